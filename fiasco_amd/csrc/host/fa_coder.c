@@ -1,0 +1,420 @@
+/*
+ *  fa_coder.c -- fiasco_coder() and the batch entry point: the host-side frame driver.
+ *
+ *  Mirrors the control flow of reference codec/coder.c:
+ *    fiasco_coder   :85-182   parameter checks, output stream, basis, price
+ *    alloc_coder    :190-366  level / limit derivation (fa_setup_params below)
+ *    get_input_image_name :390-488  "prefix[start-end{+,-}step]suffix" templates
+ *    video_coder    :490-668  frame loop (I frames only in this library build)
+ *    frame_coder    :692-892  per-frame models + partition search + write_next_wfa
+ *  Everything from subdivide() downwards runs behind fa_core_encode_frames().
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <math.h>
+#include <errno.h>
+#include "fa_host.h"
+
+static unsigned g_limit_states = FA_STOCK_STATES;
+static unsigned g_limit_level  = FA_STOCK_LEVEL;
+
+int fiasco_amd_set_limits(unsigned max_states, unsigned max_level)
+{
+    if (max_states < 16 || max_states > FA_CAP_STATES
+        || max_level < FA_STOCK_LEVEL || max_level > FA_CAP_LEVEL) {
+        fa_set_error("Limits out of range (states 16..%d, level %d..%d).",
+                     FA_CAP_STATES, FA_STOCK_LEVEL, FA_CAP_LEVEL);
+        return 0;
+    }
+    g_limit_states = max_states;
+    g_limit_level  = max_level;
+    return 1;
+}
+
+void fiasco_amd_get_limits(unsigned *max_states, unsigned *max_level)
+{
+    if (max_states) *max_states = g_limit_states;
+    if (max_level)  *max_level  = g_limit_level;
+}
+
+void fa_limits(unsigned *max_states, unsigned *max_level)
+{
+    fiasco_amd_get_limits(max_states, max_level);
+}
+
+unsigned fa_image_level(unsigned width, unsigned height)
+{
+    unsigned lx = (unsigned) (log2((double) (width - 1)) + 1);
+    unsigned ly = (unsigned) (log2((double) (height - 1)) + 1);
+    unsigned m = lx > ly ? lx : ly;
+    return m * 2 - ((ly == lx + 1) ? 1 : 0);
+}
+
+static unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+static unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+
+void fa_info_free(fa_info *wi)
+{
+    free(wi->basis_name); free(wi->title); free(wi->comment);
+    wi->basis_name = wi->title = wi->comment = NULL;
+}
+
+int fa_setup_params(const fa_options *op, float quality, unsigned width, unsigned height,
+                    int color, unsigned frames, fa_info *wi, fa_cparams *cp)
+{
+    memset(wi, 0, sizeof *wi);
+    memset(cp, 0, sizeof *cp);
+    wi->frames = frames; wi->width = width; wi->height = height; wi->color = color;
+    wi->level = fa_image_level(width, height);
+    if (wi->level > g_limit_level) {
+        /* the stock reference overruns tree_t.total[MAXLEVEL] here and crashes
+         * (SURVEY finding 2); this library reports the condition instead */
+        fa_set_error("Image level %d exceeds MAXLEVEL %d (use fiasco_amd_set_limits).",
+                     (int) wi->level, (int) g_limit_level);
+        return 0;
+    }
+    cp->level        = wi->level;
+    cp->lc_min_level = umax(op->lc_min_level, 3);
+    cp->lc_max_level = umin(op->lc_max_level, wi->level - 1);
+    if ((int) wi->level - (int) op->tiling_exponent < 6)
+        fa_warning("Image tiles must be at least 8x8 pixels large.\n"
+                   "Setting tiling size to 8x8 pixels.");
+    if (cp->lc_min_level > cp->lc_max_level) cp->lc_min_level = cp->lc_max_level;
+    wi->p_min_level = umax(op->p_min_level, cp->lc_min_level);
+    wi->p_max_level = umin(op->p_max_level, cp->lc_max_level);
+    if (wi->p_min_level > wi->p_max_level) wi->p_min_level = wi->p_max_level;
+    cp->images_level   = umin(op->images_level, cp->lc_max_level - 1);
+    cp->products_level = (unsigned) ((int) cp->lc_max_level - (int) cp->images_level - 1 > 0
+                                     ? cp->lc_max_level - cp->images_level - 1 : 0);
+    wi->max_states   = umax(umin(op->max_states, g_limit_states), 1);
+    cp->max_elements = umax(umin(op->max_elements, FA_MAXEDGES), 1);
+    cp->pool_max_states = wi->max_states;
+    wi->title   = strdup(op->title);
+    wi->comment = strdup(op->comment);
+    wi->basis_name = strdup(op->basis_name);
+    fa_rpf_init(&wi->rpf,      op->rpf_mantissa,      op->rpf_range);
+    fa_rpf_init(&wi->dc_rpf,   op->dc_rpf_mantissa,   op->dc_rpf_range);
+    fa_rpf_init(&wi->d_rpf,    op->d_rpf_mantissa,    op->d_rpf_range);
+    fa_rpf_init(&wi->d_dc_rpf, op->d_dc_rpf_mantissa, op->d_dc_rpf_range);
+    cp->rpf = wi->rpf; cp->dc_rpf = wi->dc_rpf; cp->d_rpf = wi->d_rpf; cp->d_dc_rpf = wi->d_dc_rpf;
+    wi->chroma_max_states = umax(1, op->chroma_max_states);
+    cp->chroma_max_states = wi->chroma_max_states;
+    cp->chroma_decrease   = op->chroma_decrease;
+    wi->search_range   = op->search_range;
+    wi->fps            = op->fps;
+    wi->half_pixel     = op->half_pixel_prediction;
+    wi->cross_B_search = op->half_pixel_prediction;   /* sic, codec/coder.c:359 */
+    wi->B_as_past_ref  = op->B_as_past_ref;
+    wi->smoothing      = op->smoothing;
+    cp->second_domain_block = op->second_domain_block;
+    cp->check_for_underflow = op->check_for_underflow;
+    cp->check_for_overflow  = op->check_for_overflow;
+    cp->full_search         = op->full_search;
+    cp->price        = 128 * 64 / quality;
+    cp->limit_states = g_limit_states;
+    cp->limit_level  = g_limit_level;
+    if (strcasecmp(op->id_domain_pool, "rle") != 0 || strcasecmp(op->id_rpf_model, "adaptive") != 0) {
+        fa_set_error("Only the default `rle' domain pool and `adaptive' coefficient model are built.");
+        return 0;
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------- input names */
+
+/* i-th frame name of a NULL-terminated template list; NULL past the end; *err set on a
+ * malformed template (codec/coder.c:390-488) */
+static char *input_name(char const *const *templ, unsigned ith, int *err)
+{
+    *err = 0;
+    for (; *templ; templ++) {
+        const char *t = *templ, *open = strchr(t, '[');
+        if (!open) {
+            if (ith == 0) return strdup(t);
+            ith--;
+            continue;
+        }
+        {
+            const char *s = open + 1, *s2;
+            unsigned ndig = 0;
+            int first, last, inc = 1, num;
+            for (s2 = s; isdigit((unsigned char) *s2); s2++) ndig++;
+            if (sscanf(s, "%d", &first) != 1 || first < 0 || *s2++ != '-') goto bad;
+            s = s2;
+            while (isdigit((unsigned char) *s2)) s2++;
+            if (sscanf(s, "%d", &last) != 1 || last < 0) goto bad;
+            if (*s2 == '+' || *s2 == '-') {
+                s = s2++;
+                while (isdigit((unsigned char) *s2)) s2++;
+                if (sscanf(s, "%d", &inc) != 1) goto bad;
+            }
+            if (*s2 != ']') goto bad;
+            num = first + inc * (int) ith;
+            if (num < 0) goto bad;
+            if ((inc > 0 && (unsigned) num > (unsigned) last)
+                || (inc <= 0 && (unsigned) num < (unsigned) last)) {
+                if (inc == 0) goto bad;
+                ith -= (unsigned) ((last - first) / inc + 1);
+            } else {
+                size_t plen = (size_t) (open - t);
+                char *name = (char *) malloc(plen + 32 + strlen(s2 + 1));
+                if (!name) { *err = 1; return NULL; }
+                memcpy(name, t, plen);
+                sprintf(name + plen, "%0*d%s", (int) ndig, num, s2 + 1);
+                return name;
+            }
+        }
+    }
+    return NULL;
+bad:
+    fa_set_error("Input name template conversion failure.\nCheck spelling of template.");
+    *err = 1;
+    return NULL;
+}
+
+static int frame_is_intra(unsigned display, const char *pattern, int *ok)
+{
+    int c = toupper((unsigned char) pattern[display % strlen(pattern)]);
+    *ok = 1;
+    if (display == 0) return 1;            /* first frame is forced to be intra */
+    if (c == 'I') return 1;
+    if (c != 'P' && c != 'B') {
+        fa_set_error("Frame type %c not valid. Choose one of I,B or P.", c);
+        *ok = 0;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- one still -> bytes */
+
+static int prepare_job(fa_job *job, const fa_image *im, const fa_cparams *cp, const char *basis)
+{
+    memset(job, 0, sizeof *job);
+    job->image = im;
+    job->cp    = *cp;
+    job->wfa   = fa_wfa_alloc(cp->limit_states);
+    if (!job->wfa) { fa_set_error("Out of memory!"); return 0; }
+    if (!fa_load_basis(basis, job->wfa)) return 0;
+    if (job->wfa->states >= cp->limit_states) {
+        fa_set_error("Maximum number of states reached!");
+        return 0;
+    }
+    return 1;
+}
+
+static void report(const fa_job *job, const fa_info *wi)
+{
+    int b, nb = wi->color ? 3 : 1;
+    for (b = 0; b < nb; b++) {
+        const fa_stats *s = &job->stats[b];
+        double mse = s->err / wi->width / wi->height;
+        fa_debug("WFA contains %d states (%d basis states).", (int) job->wfa->states,
+                 (int) job->wfa->basis_states);
+        fa_debug("Estimated error: %.2f (RMSE: %.2f, PSNR: %.2f dB).", (double) s->err,
+                 sqrt(mse), 10 * log(255.0 * 255.0 / mse) / log(10.0));
+        fa_debug("(T: %.0f, M: %.0f, W: %.0f)", (double) s->tree_bits, (double) s->matrix_bits,
+                 (double) s->weights_bits);
+        fa_debug("Total costs : %.2f", (double) s->costs);
+    }
+}
+
+/* ---------------------------------------------------------------- public: fiasco_coder */
+
+int fiasco_coder(char const *const *inputname, const char *outputname, float quality,
+                 const fiasco_c_options_t *options)
+{
+    static char const *const default_input[] = { "-", NULL };
+    char const *const *templ;
+    fiasco_c_options_t *defaults = NULL;
+    const fa_options *op;
+    fa_info wi;
+    fa_cparams cp;
+    fa_bitw out;
+    FILE *fout = NULL;
+    unsigned nframes = 0, i, w = 0, h = 0;
+    int color = 0, rc = 0, have_out = 0, err;
+    char **names = NULL;
+    unsigned char **bufs = NULL;
+    size_t *lens = NULL;
+    unsigned carry_min_level;
+
+    memset(&wi, 0, sizeof wi);
+    templ = (!inputname || !inputname[0] || strcmp(inputname[0], "-") == 0) ? default_input : inputname;
+    if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return 0; }
+    if (quality >= 100)
+        fa_warning("Quality typically is 1 (worst) to 100 (best).\nBe prepared for a long running time.");
+    if (options) {
+        op = fa_cast_options(options);
+        if (!op) return 0;
+    } else {
+        defaults = fiasco_c_options_new();
+        if (!defaults) return 0;
+        op = fa_cast_options(defaults);
+    }
+
+    /* output stream is opened (and truncated) before anything else can fail */
+    fout = open_file(outputname, "FIASCO_DATA", WRITE_ACCESS);
+    if (!fout) {
+        fa_set_error("Can't write outputfile `%s'.\n%s", outputname ? outputname : "<stdout>",
+                     strerror(errno));
+        goto done;
+    }
+
+    /* enumerate frames; all must agree in size and colour model */
+    for (;; nframes++) {
+        char *nm = input_name(templ, nframes, &err);
+        if (!nm) { if (err) goto done; break; }
+        names = (char **) realloc(names, (nframes + 1) * sizeof *names);
+        bufs  = (unsigned char **) realloc(bufs, (nframes + 1) * sizeof *bufs);
+        lens  = (size_t *) realloc(lens, (nframes + 1) * sizeof *lens);
+        names[nframes] = nm; bufs[nframes] = NULL; lens[nframes] = 0;
+    }
+    for (i = 0; i < nframes; i++) {
+        unsigned fw, fh; int fc; size_t off;
+        const char *nm = strcmp(names[i], "-") == 0 ? NULL : names[i];
+        bufs[i] = fa_read_whole_file(nm, "FIASCO_IMAGES", &lens[i]);
+        if (!bufs[i]) {
+            fa_set_error("Can't open frame `%s'.\n%s", names[i], strerror(errno));
+            goto done;
+        }
+        if (!fa_pnm_header(bufs[i], lens[i], names[i], &fw, &fh, &fc, &off)) goto done;
+        if (i == 0) { w = fw; h = fh; color = fc; }
+        else if (fw != w || fh != h) {
+            fa_set_error("`%s': all images of a sequence have to be of the same size.", names[i]);
+            goto done;
+        } else if (fc != color) {
+            fa_set_error("`%s': all images a sequence have to use the same color model.", names[i]);
+            goto done;
+        }
+    }
+    if (nframes == 0) { fa_set_error("Can't open frame `%s'.", "<none>"); goto done; }
+
+    if (!fa_setup_params(op, quality, w, h, color, nframes, &wi, &cp)) goto done;
+    if (op->prediction) {
+        fa_set_error("Intra prediction (ND) is not supported by this library build.");
+        goto done;
+    }
+    for (i = 0; i < nframes; i++) {
+        int ok, intra = frame_is_intra(i, op->pattern, &ok);
+        if (!ok) goto done;
+        if (!intra) {
+            fa_set_error("P/B frames (motion compensation) are not supported by this library "
+                         "build; use frame pattern `i'.");
+            goto done;
+        }
+    }
+
+    fa_bw_init(&out); have_out = 1;
+    carry_min_level = cp.lc_min_level;
+    for (i = 0; i < nframes; ) {
+        /* Gray frames are independent and go to the core as one batch; colour frames carry
+         * lc_min_level from frame to frame (codec/coder.c:785-797) and go one by one. */
+        unsigned nb = color ? 1 : nframes - i, k, good;
+        fa_job *jobs = (fa_job *) calloc(nb, sizeof *jobs);
+        fa_image **ims = (fa_image **) calloc(nb, sizeof *ims);
+        int failed = 0;
+        for (k = 0; k < nb && !failed; k++) {
+            ims[k] = fa_image_from_pnm(bufs[i + k], lens[i + k], names[i + k]);
+            if (!ims[k]) { failed = 1; break; }
+            cp.lc_min_level = carry_min_level;
+            if (!prepare_job(&jobs[k], ims[k], &cp, op->basis_name)) failed = 1;
+        }
+        if (!failed) {
+            good = (unsigned) fa_core_encode_frames(nb, jobs);
+            if (good != nb) {
+                for (k = 0; k < nb; k++)
+                    if (!jobs[k].status) { fa_set_error("%s", jobs[k].errmsg); break; }
+                failed = 1;
+            }
+        }
+        for (k = 0; k < nb && !failed; k++) {
+            report(&jobs[k], &wi);
+            if (!fa_write_frame(jobs[k].wfa, &wi, FA_I_FRAME, i + k, 0, op->normal_domains,
+                                op->delta_domains, &out))
+                failed = 1;
+            carry_min_level = jobs[k].lc_min_level_out;
+        }
+        for (k = 0; k < nb; k++) { fa_wfa_free(jobs[k].wfa); fa_image_free(ims[k]); }
+        free(jobs); free(ims);
+        if (failed) goto done;
+        i += nb;
+    }
+    {
+        size_t nbytes = fa_bw_finish(&out);
+        if (fwrite(out.buf, 1, nbytes, fout) != nbytes) {
+            fa_set_error("Can't write remaining %d bytes of bitfile!", (int) nbytes);
+            goto done;
+        }
+    }
+    rc = 1;
+done:
+    if (have_out) fa_bw_free(&out);
+    if (fout && fout != stdout) fclose(fout);
+    else if (fout) fflush(fout);
+    for (i = 0; i < nframes; i++) { free(names[i]); free(bufs ? bufs[i] : NULL); }
+    free(names); free(bufs); free(lens);
+    fa_info_free(&wi);
+    if (defaults) fiasco_c_options_delete(defaults);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- public: batch */
+
+int fiasco_amd_encode_batch(unsigned n, const unsigned char *const *pnm, const size_t *pnm_len,
+                            float quality, const fiasco_c_options_t *options,
+                            unsigned char **outv, size_t *out_len)
+{
+    fiasco_c_options_t *defaults = NULL;
+    const fa_options *op;
+    fa_job *jobs;
+    fa_image **ims;
+    fa_info *infos;
+    unsigned i, good = 0;
+    int failed = 0;
+
+    if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return 0; }
+    if (options) { op = fa_cast_options(options); if (!op) return 0; }
+    else { defaults = fiasco_c_options_new(); if (!defaults) return 0; op = fa_cast_options(defaults); }
+    if (op->prediction) {
+        fa_set_error("Intra prediction (ND) is not supported by this library build.");
+        if (defaults) fiasco_c_options_delete(defaults);
+        return 0;
+    }
+    jobs  = (fa_job *) calloc(n ? n : 1, sizeof *jobs);
+    ims   = (fa_image **) calloc(n ? n : 1, sizeof *ims);
+    infos = (fa_info *) calloc(n ? n : 1, sizeof *infos);
+    for (i = 0; i < n; i++) { outv[i] = NULL; out_len[i] = 0; }
+    for (i = 0; i < n && !failed; i++) {
+        fa_cparams cp;
+        ims[i] = fa_image_from_pnm(pnm[i], pnm_len[i], "<memory>");
+        if (!ims[i]) { failed = 1; break; }
+        if (!fa_setup_params(op, quality, ims[i]->width, ims[i]->height, ims[i]->color, 1,
+                             &infos[i], &cp)) { failed = 1; break; }
+        if (!prepare_job(&jobs[i], ims[i], &cp, op->basis_name)) failed = 1;
+    }
+    if (!failed) {
+        fa_core_encode_frames(n, jobs);
+        for (i = 0; i < n; i++) {
+            fa_bitw out;
+            if (!jobs[i].status) { fa_set_error("%s", jobs[i].errmsg); continue; }
+            fa_bw_init(&out);
+            if (fa_write_frame(jobs[i].wfa, &infos[i], FA_I_FRAME, 0, 0, op->normal_domains,
+                               op->delta_domains, &out)) {
+                out_len[i] = fa_bw_finish(&out);
+                outv[i] = (unsigned char *) malloc(out_len[i]);
+                memcpy(outv[i], out.buf, out_len[i]);
+                good++;
+            }
+            fa_bw_free(&out);
+        }
+    }
+    for (i = 0; i < n; i++) {
+        if (jobs[i].wfa) fa_wfa_free(jobs[i].wfa);
+        fa_image_free(ims[i]);
+        fa_info_free(&infos[i]);
+    }
+    free(jobs); free(ims); free(infos);
+    if (defaults) fiasco_c_options_delete(defaults);
+    return (int) good;
+}

@@ -1,0 +1,209 @@
+/*
+ *  fa_host.h -- internal host-side declarations of libfiasco_amd.
+ *
+ *  Host C keeps what the reference keeps around the hot path: options object, PNM input,
+ *  basis automaton, frame driver and the .fco stream writer.  Everything from
+ *  subdivide() downwards (partition search, matching pursuit, inner-product tables,
+ *  rate models) lives behind fa_core_encode_frames(), which is implemented
+ *    - by the HIP device coder (csrc/hip/core_hip.hip) in the product library, and
+ *    - by the CPU restatement (oracle/oracle_core.c) in the test-only oracle library.
+ */
+#ifndef FA_HOST_H
+#define FA_HOST_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include "libfiasco_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_MAXEDGES      5     /* reference codec/wfa.h:20 */
+#define FA_MAXLABELS     2     /* reference codec/wfa.h:22 */
+#define FA_STOCK_STATES  6000  /* reference codec/wfa.h:21 */
+#define FA_STOCK_LEVEL   22    /* reference codec/wfa.h:23 */
+#define FA_CAP_STATES    32000 /* word_t state ids */
+#define FA_CAP_LEVEL     26
+#define FA_NO_EDGE       (-1)
+#define FA_RANGE         (-1)
+#define FA_MAXCOSTS      1e20f /* reference codec/coder.c:53 */
+#define FA_USE_DOMAIN    2     /* reference codec/wfa.h:41 USE_DOMAIN_MASK */
+#define FA_AUXILIARY     1
+
+enum { FA_I_FRAME = 0, FA_P_FRAME = 1, FA_B_FRAME = 2 };
+enum { FA_GRAY = 0, FA_Y = 0, FA_CB = 1, FA_CR = 2 };
+
+/* level geometry, reference lib/macros.h:48-52 */
+#define fa_width_of_level(l)   (1u << ((l) >> 1))
+#define fa_height_of_level(l)  (1u << (((l) + 1) >> 1))
+#define fa_size_of_level(l)    (1u << (l))
+#define fa_address_of_level(l) (fa_size_of_level(l) - 1u)
+#define fa_size_of_tree(l)     (fa_address_of_level((l) + 1))
+
+/* ---------------- error / messages (reference lib/error.c) ---------------- */
+void fa_set_error(const char *fmt, ...);
+void fa_warning(const char *fmt, ...);
+void fa_message(const char *fmt, ...);
+void fa_debug(const char *fmt, ...);
+void fa_progress(const char *fmt, ...);
+
+/* ---------------- reduced precision format (reference lib/rpf.h) ---------------- */
+typedef struct fa_rpf {
+    unsigned mantissa_bits;
+    float    range;
+    int      range_e;
+} fa_rpf;
+void fa_rpf_init(fa_rpf *r, unsigned mantissa, int range_e);
+int  fa_rtob(float f, const fa_rpf *r);   /* used by the stream writer (weights) */
+
+/* ---------------- options (reference codec/options.h:20-65) ---------------- */
+typedef struct fa_options {
+    char     id[9];
+    char    *basis_name;
+    unsigned lc_min_level, lc_max_level;
+    unsigned p_min_level, p_max_level;
+    unsigned images_level;
+    unsigned max_states, chroma_max_states, max_elements;
+    unsigned tiling_exponent;
+    int      tiling_method;
+    char    *id_domain_pool, *id_d_domain_pool, *id_rpf_model, *id_d_rpf_model;
+    unsigned rpf_mantissa;      int rpf_range;
+    unsigned dc_rpf_mantissa;   int dc_rpf_range;
+    unsigned d_rpf_mantissa;    int d_rpf_range;
+    unsigned d_dc_rpf_mantissa; int d_dc_rpf_range;
+    float    chroma_decrease;
+    int      prediction, delta_domains, normal_domains;
+    unsigned search_range, fps;
+    char    *pattern;
+    int      half_pixel_prediction, cross_B_search, B_as_past_ref;
+    int      check_for_underflow, check_for_overflow, second_domain_block, full_search;
+    int      progress_meter;
+    char    *title, *comment;
+    unsigned smoothing;
+} fa_options;
+fa_options *fa_cast_options(const fiasco_c_options_t *o);
+
+/* ---------------- image (reference lib/image.h, 12.4 fixed point int16) ---------- */
+typedef struct fa_image {
+    unsigned width, height;
+    int      color;
+    int16_t *pixels[3];
+} fa_image;
+/* parse raw P5/P6 from memory; returns NULL + error message on failure */
+fa_image *fa_image_from_pnm(const unsigned char *buf, size_t len, const char *name);
+int       fa_pnm_header(const unsigned char *buf, size_t len, const char *name,
+                        unsigned *w, unsigned *h, int *color, size_t *data_off);
+void      fa_image_free(fa_image *im);
+unsigned char *fa_read_whole_file(const char *name, const char *env_var, size_t *len);
+
+/* ---------------- automaton container handed to the writer ---------------- */
+typedef struct fa_wfa {
+    unsigned cap;                 /* allocated states */
+    unsigned states, basis_states, root_state;
+    int      frame_type;
+    float   *final_distribution;  /* [cap] */
+    uint8_t *level_of_state;      /* [cap] */
+    uint8_t *domain_type;         /* [cap] */
+    uint8_t *delta_state;         /* [cap] */
+    int16_t *tree;                /* [cap][2] */
+    uint16_t *x, *y;              /* [cap][2] */
+    int16_t *into;                /* [cap][2][6] */
+    float   *weight;              /* [cap][2][6] */
+    int16_t *y_state;             /* [cap][2] */
+    uint8_t *y_column;            /* [cap][2] */
+    uint8_t *prediction;          /* [cap][2] */
+} fa_wfa;
+#define FA_TREE(w, s, l)      ((w)->tree[(s) * 2 + (l)])
+#define FA_INTO(w, s, l, e)   ((w)->into[((s) * 2 + (l)) * 6 + (e)])
+#define FA_WEIGHT(w, s, l, e) ((w)->weight[((s) * 2 + (l)) * 6 + (e)])
+fa_wfa *fa_wfa_alloc(unsigned cap);
+void    fa_wfa_free(fa_wfa *w);
+void    fa_wfa_remove_states(fa_wfa *w, unsigned from);
+void    fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, unsigned label);
+int     fa_load_basis(const char *name, fa_wfa *w);   /* 1 ok / 0 error */
+
+/* ---------------- stream info (reference codec/wfa.h:65-110 wfa_info_t) ----------- */
+typedef struct fa_info {
+    char    *basis_name, *title, *comment;
+    unsigned max_states, chroma_max_states;
+    int      color;
+    unsigned width, height, level;
+    fa_rpf   rpf, dc_rpf, d_rpf, d_dc_rpf;
+    unsigned frames, fps, p_min_level, p_max_level, search_range;
+    int      half_pixel, cross_B_search, B_as_past_ref;
+    unsigned smoothing;
+} fa_info;
+
+/* ---------------- parameters of one frame for the core coder ---------------- */
+typedef struct fa_cparams {
+    float    price;                       /* 128*64/quality (codec/coder.c:164) */
+    unsigned lc_min_level, lc_max_level;  /* after clamping (codec/coder.c:261-281) */
+    unsigned images_level, products_level;
+    unsigned max_elements;
+    unsigned pool_max_states;             /* wi->max_states */
+    unsigned chroma_max_states;
+    float    chroma_decrease;
+    fa_rpf   rpf, dc_rpf, d_rpf, d_dc_rpf;
+    int      second_domain_block, check_for_underflow, check_for_overflow, full_search;
+    unsigned level;                       /* bintree level of the whole image */
+    unsigned limit_states, limit_level;   /* MAXSTATES / MAXLEVEL in force */
+} fa_cparams;
+
+/* result statistics of one coded band (root range), used for -V 2 style reporting */
+typedef struct fa_stats {
+    float costs, err, tree_bits, matrix_bits, weights_bits;
+} fa_stats;
+
+typedef struct fa_job {
+    const fa_image   *image;      /* in  */
+    fa_cparams        cp;         /* in  (lc_min_level may be ratcheted: colour) */
+    fa_wfa           *wfa;        /* in: basis states loaded; out: finished automaton */
+    fa_stats          stats[3];   /* out */
+    int               status;     /* out: 1 ok, 0 failed */
+    char              errmsg[160];/* out */
+    unsigned          lc_min_level_out; /* out: value of options.lc_min_level after the
+                                           frame (colour carry, codec/coder.c:785-797) */
+} fa_job;
+
+/* THE SEAM.  Encode n independent frames.  Returns number of successful jobs. */
+int fa_core_encode_frames(unsigned n, fa_job *jobs);
+const char *fa_core_name(void);
+
+/* ---------------- bit writer (reference lib/bit-io.c, memory backed) -------------- */
+typedef struct fa_bitw {
+    unsigned char *buf;
+    size_t   cap;
+    size_t   bytes;      /* index of current byte + 1 (0 before the first bit) */
+    unsigned bitpos;     /* reference semantics: 8 initially, counts down      */
+    unsigned long long nbits;
+} fa_bitw;
+void fa_bw_init(fa_bitw *b);
+void fa_bw_free(fa_bitw *b);
+void fa_bw_put_bit(fa_bitw *b, unsigned v);
+void fa_bw_put_bits(fa_bitw *b, unsigned v, unsigned n);
+void fa_bw_align(fa_bitw *b);
+size_t fa_bw_finish(fa_bitw *b);   /* number of bytes the reference would write */
+void fa_bw_rice(fa_bitw *b, unsigned value, unsigned k);
+void fa_bw_bincode(fa_bitw *b, unsigned value, unsigned maxval);
+
+/* ---------------- .fco writer (reference output/ directory) ---------------- */
+void fa_write_header(const fa_info *wi, fa_bitw *out);
+/* returns 1 ok, 0 on the reference's "total != ..." sanity error */
+int  fa_write_frame(const fa_wfa *wfa, const fa_info *wi, int frame_type, unsigned number,
+                    int prediction, int normal_domains, int delta_domains, fa_bitw *out);
+/* stable (count desc, state asc) top-n hits, reference codec/wfalib.c:182-231 */
+int16_t *fa_compute_hits(unsigned from, unsigned to, unsigned n, const fa_wfa *wfa);
+
+/* ---------------- frame driver pieces shared by fiasco_coder and the batch API ----- */
+unsigned fa_image_level(unsigned width, unsigned height);      /* codec/coder.c:247-255 */
+int fa_setup_params(const fa_options *op, float quality, unsigned width, unsigned height,
+                    int color, unsigned frames, fa_info *wi, fa_cparams *cp);
+void fa_info_free(fa_info *wi);
+void fa_limits(unsigned *max_states, unsigned *max_level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

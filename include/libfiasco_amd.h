@@ -1,0 +1,126 @@
+/*
+ *  libfiasco_amd.h -- C ABI of the MI355X-native FIASCO encoder library.
+ *
+ *  This is the drop-in boundary: a C-ABI shared library whose encoder
+ *  entry points have the same names, argument meaning, return convention (1 = ok,
+ *  0 = failure + fiasco_get_error_message()) and the same struct layouts as the
+ *  reference's public header, so that the reference's `cfiasco` objects link against it
+ *  unchanged.  Each declaration cites the reference interface it replaces.
+ *
+ *  Only the ENCODER side is provided (hot path = encode-side matching pursuit).
+ *  Decoder / image / renderer entry points of the reference (fiasco.h:223-296) are out of
+ *  scope and not exported.
+ */
+#ifndef LIBFIASCO_AMD_H
+#define LIBFIASCO_AMD_H 1
+
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: values are ABI (reference fiasco.h:56-80) ---- */
+typedef enum { FIASCO_NO_VERBOSITY, FIASCO_SOME_VERBOSITY,
+               FIASCO_ULTIMATE_VERBOSITY } fiasco_verbosity_e;
+typedef enum { FIASCO_TILING_SPIRAL_ASC, FIASCO_TILING_SPIRAL_DSC,
+               FIASCO_TILING_VARIANCE_ASC, FIASCO_TILING_VARIANCE_DSC } fiasco_tiling_e;
+typedef enum { FIASCO_RPF_RANGE_0_75, FIASCO_RPF_RANGE_1_00,
+               FIASCO_RPF_RANGE_1_50, FIASCO_RPF_RANGE_2_00 } fiasco_rpf_range_e;
+typedef enum { FIASCO_PROGRESS_NONE, FIASCO_PROGRESS_BAR,
+               FIASCO_PROGRESS_PERCENT } fiasco_progress_e;
+
+/* ---- coder options object: vtable order is ABI (reference fiasco.h:132-174) ---- */
+typedef struct fiasco_c_options {
+    void (*delete_)(struct fiasco_c_options *o);   /* reference member name: delete */
+    int (*set_tiling)(struct fiasco_c_options *o, fiasco_tiling_e method, unsigned exponent);
+    int (*set_frame_pattern)(struct fiasco_c_options *o, const char *pattern);
+    int (*set_basisfile)(struct fiasco_c_options *o, const char *filename);
+    int (*set_chroma_quality)(struct fiasco_c_options *o, float quality_factor,
+                              unsigned dictionary_size);
+    int (*set_optimizations)(struct fiasco_c_options *o, unsigned min_block_level,
+                             unsigned max_block_level, unsigned max_elements,
+                             unsigned dictionary_size, unsigned optimization_level);
+    int (*set_prediction)(struct fiasco_c_options *o, int intra_prediction,
+                          unsigned min_block_level, unsigned max_block_level);
+    int (*set_video_param)(struct fiasco_c_options *o, unsigned frames_per_second,
+                           int half_pixel_prediction, int cross_B_search, int B_as_past_ref);
+    int (*set_quantization)(struct fiasco_c_options *o, unsigned mantissa,
+                            fiasco_rpf_range_e range, unsigned dc_mantissa,
+                            fiasco_rpf_range_e dc_range);
+    int (*set_progress_meter)(struct fiasco_c_options *o, fiasco_progress_e type);
+    int (*set_smoothing)(struct fiasco_c_options *o, int smoothing);
+    int (*set_comment)(struct fiasco_c_options *o, const char *comment);
+    int (*set_title)(struct fiasco_c_options *o, const char *title);
+    void *private_;                                /* reference member name: private */
+} fiasco_c_options_t;
+
+/* ---- misc (reference fiasco.h:210-216, lib/error.c:178-186,300-310) ---- */
+const char *fiasco_get_error_message(void);
+void fiasco_set_verbosity(fiasco_verbosity_e level);
+fiasco_verbosity_e fiasco_get_verbosity(void);
+
+/* ---- the encoder entry point (reference fiasco.h:303-306, codec/coder.c:85-182) ----
+ * inputname: NULL-terminated list of raw PGM/PPM names or "prefix[a-b{+,-}s]suffix"
+ * templates; outputname NULL or "-" = stdout; quality > 0; options may be NULL.       */
+int fiasco_coder(char const *const *inputname, const char *outputname, float quality,
+                 const fiasco_c_options_t *options);
+
+/* ---- options constructor / setters (reference fiasco.h:313-398, codec/options.c) ---- */
+fiasco_c_options_t *fiasco_c_options_new(void);
+void fiasco_c_options_delete(fiasco_c_options_t *options);
+int fiasco_c_options_set_smoothing(fiasco_c_options_t *options, int smoothing);
+int fiasco_c_options_set_frame_pattern(fiasco_c_options_t *options, const char *pattern);
+int fiasco_c_options_set_tiling(fiasco_c_options_t *options, fiasco_tiling_e method,
+                                unsigned exponent);
+int fiasco_c_options_set_basisfile(fiasco_c_options_t *options, const char *filename);
+int fiasco_c_options_set_chroma_quality(fiasco_c_options_t *options, float quality_factor,
+                                        unsigned dictionary_size);
+int fiasco_c_options_set_optimizations(fiasco_c_options_t *options, unsigned min_block_level,
+                                       unsigned max_block_level, unsigned max_elements,
+                                       unsigned dictionary_size, unsigned optimization_level);
+int fiasco_c_options_set_prediction(fiasco_c_options_t *options, int intra_prediction,
+                                    unsigned min_block_level, unsigned max_block_level);
+int fiasco_c_options_set_video_param(fiasco_c_options_t *options, unsigned frames_per_second,
+                                     int half_pixel_prediction, int cross_B_search,
+                                     int B_as_past_ref);
+int fiasco_c_options_set_quantization(fiasco_c_options_t *options, unsigned mantissa,
+                                      fiasco_rpf_range_e range, unsigned dc_mantissa,
+                                      fiasco_rpf_range_e dc_range);
+int fiasco_c_options_set_progress_meter(fiasco_c_options_t *options, fiasco_progress_e type);
+int fiasco_c_options_set_comment(fiasco_c_options_t *options, const char *comment);
+int fiasco_c_options_set_title(fiasco_c_options_t *options, const char *title);
+
+/* ---- two non-public symbols the reference CLI objects import (nm cwfa.o params.o;
+ *      reference lib/misc.c:51-71, lib/bit-io.c:48-146) ---- */
+void *fiasco_calloc(size_t n, size_t size);
+typedef enum { READ_ACCESS, WRITE_ACCESS } openmode_e;
+FILE *open_file(const char *filename, const char *env_var, openmode_e mode);
+
+/* =====================================================================================
+ *  Extensions of this library (not in the reference).  Plain pointers and sizes only.
+ * ===================================================================================== */
+
+/* Limits extension: the reference hard-codes MAXSTATES 6000 /
+ * MAXLEVEL 22 (codec/wfa.h:21,23), which rules out 4K frames and 1080p colour at CLI
+ * defaults.  Default here = the stock limits (bit parity with the stock reference).
+ * max_states in [16, 32000], max_level in [22, 26].  Returns 1 on success.            */
+int fiasco_amd_set_limits(unsigned max_states, unsigned max_level);
+void fiasco_amd_get_limits(unsigned *max_states, unsigned *max_level);
+
+/* Batch encoder: encode `n` independent still images (raw PNM bytes in host memory) into
+ * `n` .fco byte strings, all frames in flight on the GPU at once (one persistent
+ * workgroup per frame).  Semantically identical to n separate fiasco_coder() calls.
+ * out[i] is malloc()ed by the library (caller frees with fiasco_amd_free), out_len[i] its
+ * length.  Returns the number of frames encoded successfully (== n on success).        */
+int fiasco_amd_encode_batch(unsigned n, const unsigned char *const *pnm,
+                            const size_t *pnm_len, float quality,
+                            const fiasco_c_options_t *options,
+                            unsigned char **out, size_t *out_len);
+void fiasco_amd_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBFIASCO_AMD_H */

@@ -1,0 +1,1089 @@
+/*
+ *  oracle_core.c -- TEST INFRASTRUCTURE: CPU restatement of the FIASCO encode-side hot
+ *  path (partition search + matching pursuit + inner-product tables + rate models).
+ *
+ *  This file is the parity oracle for the HIP device coder.  It is NOT part of the
+ *  product: only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may
+ *  link or call it (it is built into oracle/liboracle_fiasco.so together with the host
+ *  stream writer, never into libfiasco_amd.so).
+ *
+ *  Pinning: the .fco streams produced through this core are checked byte-for-byte
+ *  against (a) the md5 / size known answers recorded in SURVEY.md §8c / Appendix C and
+ *  (b) the committed golden streams under tests/golden/ that were generated with the
+ *  real reference built by oracle/ref_build.sh (tests/test_oracle_pins.py).
+ *
+ *  Each function cites the reference file:line whose arithmetic it restates; float
+ *  evaluation order is kept (sequential sums, no FMA: build with -ffp-contract=off).
+ *  Single threaded, one frame at a time, plain C.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+#include "fa_host.h"
+
+#define MAXED FA_MAXEDGES
+
+/* ------------------------------------------------------------------ models */
+
+/* "rle" domain-pool model, codec/domain-pool.c:621-630 (+ nested 1-domain qac model).
+ * The states[] list is append-only along any live lineage of snapshots, so snapshots
+ * share one array and differ only in n (see DESIGN.md "model snapshots"). */
+typedef struct rle_model {
+    int16_t  count[MAXED + 1];
+    uint16_t total, n, max_domains, y_index;
+    int16_t  d0_index;      /* qac model of domain 0: probability index */
+    uint16_t d0_yindex;
+    uint16_t d0_n;          /* 0 or 1 */
+} rle_model;
+
+typedef struct range {
+    unsigned x, y, image, address, level, global_address;
+    float    weight[MAXED + 1];
+    int16_t  into[MAXED + 1];
+    int      tree;
+    float    err, tree_bits, matrix_bits, weights_bits;
+} range;
+
+typedef struct mpres {
+    int16_t exclude[MAXED];
+    int16_t indices[MAXED + 1];
+    int16_t into[MAXED + 1];
+    float   weight[MAXED];
+    float   matrix_bits, weights_bits, err, costs;
+} mpres;
+
+typedef struct oc {
+    const fa_cparams *cp;
+    const fa_image   *im;
+    fa_wfa           *w;
+    unsigned lc_min, lc_max, images_level, products_level, max_elements;
+    unsigned nimg, nprod, nlev;         /* table sizes */
+    float    price;
+    float   *images;                    /* [cap][nimg]  state images, levels 0..images_level */
+    float   *ipis;                      /* [cap][nprod] <range sub-block, state> heap table  */
+    float  **gram;                      /* [cap] -> nlev rows of (s+1) floats                */
+    float   *pixels;                    /* 2^lc_max pixels of the current block, tree order  */
+    unsigned ML;                        /* MAXLEVEL in force                                 */
+    unsigned *tm;                       /* tree models: counts,total,p_counts,p_total [4*ML] */
+    rle_model pool;
+    int16_t  *pool_states;              /* shared states[] of the pool lineage */
+    int16_t  *coeff;                    /* aac counts: [dc symbols][level][symbols] */
+    int16_t  *coeff_totals;             /* [1 + levels] */
+    unsigned  coeff_min, coeff_max, coeff_size, coeff_nt;
+    float     m0[1024], m1[1024];       /* qac bit tables */
+    /* matching-pursuit scratch, indexed by POSITION in the domain list */
+    float    *rem_num, *rem_den, *ipdo; /* ipdo[d*MAXED + k] */
+    uint8_t  *used;
+    int16_t  *dlist;
+    float     norm_ov[MAXED + 1], ipio[MAXED + 1];
+    char      err[160];
+    int       failed;
+} oc;
+
+static float *img_of(oc *c, unsigned s) { return c->images + (size_t) s * c->nimg; }
+static float *ipis_of(oc *c, unsigned s) { return c->ipis + (size_t) s * c->nprod; }
+static int need_image(const fa_wfa *w, unsigned s) { return w->domain_type[s] != 0; }
+static int usedomain(const fa_wfa *w, int s) { return w->domain_type[s] & FA_USE_DOMAIN; }
+
+/* ------------------------------------------------------------------ rpf  (lib/rpf.c:59-169) */
+
+static float btor(int b, const fa_rpf *r)
+{
+    uint32_t mant, bits;
+    int sign, expo = 0;
+    float v;
+    if (b == -1) return 0;
+    sign = b & 1;
+    mant = ((uint32_t) b & ((1u << (r->mantissa_bits + 1)) - 1)) >> 1;
+    mant <<= (23 - r->mantissa_bits);
+    if (mant == 0)
+        v = sign ? -1.0f : 1.0f;
+    else {
+        while (!(mant & (1u << 22))) { expo--; mant <<= 1; }
+        mant <<= 1;
+        bits = ((uint32_t) sign << 31) | ((uint32_t) (expo + 126) << 23) | (mant & 0x7fffffu);
+        memcpy(&v, &bits, 4);
+    }
+    return v * r->range;
+}
+
+static float quant(float f, const fa_rpf *r) { return btor(fa_rtob(f, r), r); }
+
+/* ------------------------------------------------------------------ tree model (codec/bintree.c) */
+
+static void tree_init(unsigned *counts, unsigned *total, unsigned ML)
+{
+    static const unsigned c0[22] = {20,17,15,10,5,4,3,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1};
+    static const unsigned c1[22] = {1,1,1,1,1,1,1,1,1,2,3,5,10,15,20,25,30,35,60,60,60,60};
+    unsigned l;
+    for (l = 0; l < ML; l++) {
+        unsigned k = l < 22 ? l : 21;          /* limits extension: clamp */
+        counts[l] = c1[k];
+        total[l]  = c0[k] + c1[k];
+    }
+}
+
+/* which: 0 = tree model, 1 = prediction tree model.  Index `level` may equal ML at the
+ * image root of a level-22 image: it then aliases the next array exactly like the
+ * reference's out-of-bounds read (codec/subdivide.c:253). */
+static float tree_bits(const oc *c, int child, unsigned level, int which)
+{
+    const unsigned *counts = c->tm + (size_t) which * 2 * c->ML;
+    float prob = counts[level] / (float) counts[c->ML + level];
+    return child ? (float) -log2(prob) : (float) -log2(1 - prob);
+}
+
+static void tree_update(oc *c, int child, unsigned level, int which)
+{
+    unsigned *counts = c->tm + (size_t) which * 2 * c->ML;
+    if (child) counts[level]++;
+    counts[c->ML + level]++;
+}
+
+/* ------------------------------------------------------------------ qac tables (domain-pool.c:970-999) */
+
+static void init_matrix_tables(oc *c)
+{
+    unsigned idx = 0, n, e;
+    for (n = 1; n <= 9; n++)
+        for (e = 0; e < (1u << n); e++, idx++) {
+            c->m1[idx] = (float) -log2(1 / (float) (1 << n));
+            c->m0[idx] = (float) -log2(1 - 1 / (float) (1 << n));
+        }
+    for (; idx < 1024; idx++) c->m0[idx] = c->m1[idx] = 0;
+}
+
+/* ------------------------------------------------------------------ rle pool (domain-pool.c:621-879) */
+
+static void pool_init(oc *c)
+{
+    unsigned m, s;
+    memset(&c->pool, 0, sizeof c->pool);
+    for (m = 0; m < MAXED + 1; m++) { c->pool.count[m] = 1; c->pool.total++; }
+    c->pool.max_domains = (uint16_t) c->cp->pool_max_states;
+    for (s = 0; s < c->w->basis_states; s++)
+        if (usedomain(c->w, (int) s)) {
+            if (c->pool.n < c->pool.max_domains) {
+                c->pool_states[c->pool.n++] = (int16_t) s;
+                if (s == 0) { c->pool.d0_index = 0; c->pool.d0_n = 1; }
+            }
+        }
+}
+
+static int pool_append(oc *c, unsigned state)
+{
+    if (c->pool.n >= c->pool.max_domains) return 0;
+    c->pool_states[c->pool.n++] = (int16_t) state;
+    return 1;
+}
+
+/* -1 terminated candidate list: the pool states plus the co-located Y state if usable
+ * and not already present (rle_generate :707-735).  Returns the list length. */
+static unsigned pool_generate(oc *c, int y_state, int16_t *out)
+{
+    unsigned n, len = c->pool.n;
+    int present = 0;
+    if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
+    memcpy(out, c->pool_states, len * sizeof(int16_t));
+    for (n = 0; n < len; n++) if (out[n] == y_state) present = 1;
+    if (!present && y_state >= 0) out[len++] = (int16_t) y_state;
+    out[len] = -1;
+    return len;
+}
+
+static unsigned bits_bin_code(unsigned value, unsigned maxval)
+{
+    unsigned k = 0, v = maxval + 1, r;
+    while (v >>= 1) k++;
+    r = (maxval + 1) % (1u << k);
+    return value < maxval + 1 - 2 * r ? k : k + 1;
+}
+
+/* price of the nested domain-0 model: qac_bits(:367-402) on a 1-domain list */
+static float d0_bits(const oc *c, const rle_model *m, int y_state, int uses0)
+{
+    float b = 0;
+    if (m->d0_n && 0 != y_state) b += c->m0[m->d0_index];
+    if (y_state >= 0) b += c->m0[m->d0_yindex];
+    if (uses0) {
+        if (0 == y_state) { b -= c->m0[m->d0_yindex]; b += c->m1[m->d0_yindex]; }
+        else              { b -= c->m0[m->d0_index];  b += c->m1[m->d0_index]; }
+    }
+    return b;
+}
+
+/* rle_bits :737-793.  `used` = -1 terminated list of POSITIONS in `domains`, or NULL. */
+static float pool_bits(const oc *c, const int16_t *domains, const int16_t *used, int y_state)
+{
+    const rle_model *m = &c->pool;
+    int16_t sorted[MAXED + 1];
+    unsigned n = 0, e, last;
+    float bits;
+    if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
+    if (used) {
+        for (e = 0; used[e] != FA_NO_EDGE; e++)
+            if (domains[used[e]] != y_state) sorted[n++] = used[e];
+        /* the y-state terms the reference accumulates here are overwritten at :772 */
+        for (e = 1; e < n; e++) {                     /* insertion sort, ascending */
+            int16_t v = sorted[e]; unsigned j = e;
+            while (j > 0 && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; j--; }
+            sorted[j] = v;
+        }
+    }
+    bits = (float) -log2(m->count[n] / (float) m->total);
+    bits += d0_bits(c, m, y_state, used && n && sorted[0] == 0);
+    last = 1;
+    for (e = 0; e < n; e++) {
+        int into = sorted[e];
+        if (into && (unsigned) m->n - 1 - last) {
+            bits += bits_bin_code((unsigned) into - last, (unsigned) m->n - 1 - last);
+            last = (unsigned) into + 1;
+        }
+    }
+    return bits;
+}
+
+/* rle_update :795-830 with the nested qac_update :404-446 */
+static void pool_update(oc *c, const int16_t *domains, const int16_t *used, int y_state)
+{
+    rle_model *m = &c->pool;
+    int state_0 = 0, state_y = 0;
+    unsigned edge = 0;
+    if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
+    if (used)
+        for (edge = 0; used[edge] != FA_NO_EDGE; edge++) {
+            if (domains[used[edge]] == 0) state_0 = 1;
+            else if (domains[used[edge]] == y_state) state_y = 1;
+        }
+    m->count[edge]++;
+    m->total++;
+    {   /* domain-0 model */
+        int used_y = 0, y_is_domain = 0;
+        if (m->d0_n) { m->d0_index++; if (0 == y_state) y_is_domain = 1; }
+        if (state_0) {
+            if (0 == y_state) { if (y_is_domain) m->d0_index--; m->d0_yindex >>= 1; used_y = 1; }
+            else { m->d0_index--; m->d0_index >>= 1; }
+        }
+        if (y_state >= 0 && !used_y) m->d0_yindex++;
+        if (m->d0_n && m->d0_index > 1020) m->d0_index = 1020;
+        if (m->d0_yindex > 1020) m->d0_yindex = 1020;
+    }
+    if (state_y) m->y_index >>= 1; else m->y_index++;
+    if (m->y_index > 1020) m->y_index = 1020;
+}
+
+/* rle_chroma :854-879 */
+static void pool_chroma(oc *c)
+{
+    rle_model *m = &c->pool;
+    unsigned maxd = c->cp->chroma_max_states;
+    if (maxd < m->n) {
+        int16_t *dom = fa_compute_hits(c->w->basis_states, c->w->states - 1, maxd, c->w);
+        unsigned n;
+        for (n = 0; n < maxd && dom[n] >= 0; n++) c->pool_states[n] = dom[n];
+        if (n < maxd) maxd = n;
+        free(dom);
+        m->n = (uint16_t) maxd;
+    }
+    m->y_index = 0;
+    m->max_domains = m->n;
+}
+
+/* ------------------------------------------------------------------ aac coefficient model (coeff.c:190-326) */
+
+static void coeff_init(oc *c)
+{
+    unsigned dcs = 1u << (1 + c->cp->dc_rpf.mantissa_bits), sy = 1u << (1 + c->cp->rpf.mantissa_bits);
+    unsigned i;
+    c->coeff_min = c->lc_min; c->coeff_max = c->lc_max;
+    c->coeff_size = (c->coeff_max - c->coeff_min + 1) * sy + dcs;
+    c->coeff_nt = c->coeff_max - c->coeff_min + 2;
+    c->coeff = (int16_t *) malloc(c->coeff_size * sizeof(int16_t));
+    c->coeff_totals = (int16_t *) malloc(c->coeff_nt * sizeof(int16_t));
+    for (i = 0; i < c->coeff_size; i++) c->coeff[i] = 1;
+    c->coeff_totals[0] = (int16_t) dcs;
+    for (i = 1; i < c->coeff_nt; i++) c->coeff_totals[i] = (int16_t) sy;
+}
+
+static int16_t *coeff_ctx(const oc *c, unsigned level)
+{
+    return c->coeff + (1u << (1 + c->cp->dc_rpf.mantissa_bits))
+           + (level - c->coeff_min) * (1u << (1 + c->cp->rpf.mantissa_bits));
+}
+
+static float coeff_bits(const oc *c, const float *wt, const int16_t *states, unsigned level)
+{
+    float bits = 0;
+    const int16_t *ctx = coeff_ctx(c, level);
+    unsigned e;
+    for (e = 0; states[e] != FA_NO_EDGE; e++)
+        if (states[e])
+            bits -= log2(ctx[fa_rtob(wt[e], &c->cp->rpf)]
+                         / (float) c->coeff_totals[level - c->coeff_min + 1]);
+        else
+            bits -= log2(c->coeff[fa_rtob(wt[e], &c->cp->dc_rpf)] / (float) c->coeff_totals[0]);
+    return bits;
+}
+
+static void coeff_update(oc *c, const float *wt, const int16_t *states, unsigned level)
+{
+    int16_t *ctx = coeff_ctx(c, level);
+    unsigned e;
+    for (e = 0; states[e] != FA_NO_EDGE; e++)
+        if (states[e]) {
+            ctx[fa_rtob(wt[e], &c->cp->rpf)]++;
+            c->coeff_totals[level - c->coeff_min + 1]++;
+        } else {
+            c->coeff[fa_rtob(wt[e], &c->cp->dc_rpf)]++;
+            c->coeff_totals[0]++;
+        }
+}
+
+/* ------------------------------------------------------------------ inner products (codec/ip.c) */
+
+static float dot_image_state(oc *c, unsigned address, unsigned level, unsigned dom)
+{
+    const float *p = c->pixels + (size_t) address * fa_size_of_level(level);
+    const float *s = img_of(c, dom) + fa_address_of_level(level);
+    float ip = 0;
+    unsigned i;
+    for (i = fa_size_of_level(level); i; i--) ip += *p++ * *s++;
+    return ip;
+}
+
+static float dot_state_state(oc *c, unsigned d1, unsigned d2, unsigned level)
+{
+    const float *a = img_of(c, d1) + fa_address_of_level(level);
+    const float *b = img_of(c, d2) + fa_address_of_level(level);
+    float ip = 0;
+    unsigned i;
+    for (i = fa_size_of_level(level); i; i--) ip += *a++ * *b++;
+    return ip;
+}
+
+static float ip_image_state(oc *c, unsigned image, unsigned address, unsigned level, unsigned dom)
+{
+    if (level <= c->images_level) return dot_image_state(c, address, level, dom);
+    return ipis_of(c, dom)[image];
+}
+
+static float ip_state_state(oc *c, unsigned d1, unsigned d2, unsigned level)
+{
+    unsigned hi, lo;
+    if (level <= c->images_level) return dot_state_state(c, d1, d2, level);
+    hi = d1 > d2 ? d1 : d2; lo = d1 > d2 ? d2 : d1;
+    return c->gram[hi][(size_t) (level - c->images_level - 1) * (hi + 1) + lo];
+}
+
+/* ip.c:72-154: tables <sub-block, state> for states from..states-1, all sub-blocks of
+ * `image` down to images_level+1; per slot the additions run label 0 {child, edges},
+ * label 1 {child, edges} */
+static void compute_ip_images_state(oc *c, unsigned image, unsigned address, unsigned level,
+                                    unsigned n, unsigned from)
+{
+    const fa_wfa *w = c->w;
+    unsigned label, state;
+    if (level <= c->images_level) return;
+    if (level > c->images_level + 1)
+        compute_ip_images_state(c, 2 * image + 1, address * 2, level - 1, 2 * n, from);
+    for (label = 0; label < 2; label++)
+        for (state = from; state < w->states; state++) {
+            unsigned edge, cnt;
+            int dom;
+            float *dst;
+            if (!need_image(w, state)) continue;
+            if ((dom = FA_TREE(w, state, label)) != FA_RANGE) {
+                dst = ipis_of(c, state) + image;
+                if (level > c->images_level + 1) {
+                    const float *src = ipis_of(c, (unsigned) dom) + image * 2 + label + 1;
+                    for (cnt = n; cnt; cnt--, src += 2) *dst++ += *src;
+                } else {
+                    unsigned adr = address * 2 + label;
+                    for (cnt = n; cnt; cnt--, adr += 2)
+                        *dst++ += dot_image_state(c, adr, level - 1, (unsigned) dom);
+                }
+            }
+            for (edge = 0; (dom = FA_INTO(w, state, label, edge)) != FA_NO_EDGE; edge++) {
+                float wt = FA_WEIGHT(w, state, label, edge);
+                dst = ipis_of(c, state) + image;
+                if (level > c->images_level + 1) {
+                    const float *src = ipis_of(c, (unsigned) dom) + image * 2 + label + 1;
+                    for (cnt = n; cnt; cnt--, src += 2) *dst++ += *src * wt;
+                } else {
+                    unsigned adr = address * 2 + label;
+                    for (cnt = n; cnt; cnt--, adr += 2)
+                        *dst++ += wt * dot_image_state(c, adr, level - 1, (unsigned) dom);
+                }
+            }
+        }
+}
+
+/* ip.c:184-260: Gram rows of states from..to at levels images_level+1 .. lc_max */
+static void compute_ip_states_state(oc *c, unsigned from, unsigned to)
+{
+    const fa_wfa *w = c->w;
+    unsigned level, s1, s2;
+    for (level = c->images_level + 1; level <= c->lc_max; level++)
+        for (s1 = from; s1 <= to; s1++)
+            for (s2 = 0; s2 <= s1; s2++) {
+                unsigned label;
+                float ip = 0;
+                if (!need_image(w, s2)) continue;
+                for (label = 0; label < 2; label++) {
+                    int d1, d2;
+                    unsigned e1, e2;
+                    float sum;
+                    if ((d1 = FA_TREE(w, s1, label)) != FA_RANGE) {
+                        sum = 0;
+                        if ((d2 = FA_TREE(w, s2, label)) != FA_RANGE)
+                            sum = ip_state_state(c, (unsigned) d1, (unsigned) d2, level - 1);
+                        for (e2 = 0; (d2 = FA_INTO(w, s2, label, e2)) != FA_NO_EDGE; e2++)
+                            sum += FA_WEIGHT(w, s2, label, e2)
+                                   * ip_state_state(c, (unsigned) d1, (unsigned) d2, level - 1);
+                        ip += sum;
+                    }
+                    for (e1 = 0; (d1 = FA_INTO(w, s1, label, e1)) != FA_NO_EDGE; e1++) {
+                        float w1 = FA_WEIGHT(w, s1, label, e1);
+                        sum = 0;
+                        if ((d2 = FA_TREE(w, s2, label)) != FA_RANGE)
+                            sum = ip_state_state(c, (unsigned) d1, (unsigned) d2, level - 1);
+                        for (e2 = 0; (d2 = FA_INTO(w, s2, label, e2)) != FA_NO_EDGE; e2++)
+                            sum += FA_WEIGHT(w, s2, label, e2)
+                                   * ip_state_state(c, (unsigned) d1, (unsigned) d2, level - 1);
+                        ip += w1 * sum;
+                    }
+                }
+                c->gram[s1][(size_t) (level - c->images_level - 1) * (s1 + 1) + s2] = ip;
+            }
+}
+
+/* ------------------------------------------------------------------ states (codec/control.c) */
+
+/* control.c:205-258: state images at levels 1..images_level from the children's */
+static void compute_images(oc *c, unsigned from, unsigned to)
+{
+    const fa_wfa *w = c->w;
+    unsigned level, state, label;
+    for (level = 1; level <= c->images_level; level++)
+        for (state = from; state <= to; state++)
+            for (label = 0; label < 2; label++) {
+                unsigned half = fa_size_of_level(level - 1), edge, i;
+                float *dst = img_of(c, state) + fa_address_of_level(level) + label * half;
+                int dom;
+                if ((dom = FA_TREE(w, state, label)) != FA_RANGE)
+                    memcpy(dst, img_of(c, (unsigned) dom) + fa_address_of_level(level - 1),
+                           half * sizeof(float));
+                for (edge = 0; (dom = FA_INTO(w, state, label, edge)) != FA_NO_EDGE; edge++) {
+                    const float *src = img_of(c, (unsigned) dom) + fa_address_of_level(level - 1);
+                    float wt = FA_WEIGHT(w, state, label, edge);
+                    for (i = 0; i < half; i++) dst[i] += src[i] * wt;
+                }
+            }
+}
+
+static void alloc_tables(oc *c, unsigned s)
+{
+    memset(img_of(c, s), 0, c->nimg * sizeof(float));
+    memset(ipis_of(c, s), 0, c->nprod * sizeof(float));
+    free(c->gram[s]);
+    c->gram[s] = (float *) calloc((size_t) c->nlev * (s + 1) + 1, sizeof(float));
+}
+
+static void fail(oc *c, const char *msg)
+{
+    if (!c->failed) { c->failed = 1; snprintf(c->err, sizeof c->err, "%s", msg); }
+}
+
+/* control.c:48-131 */
+static void append_state(oc *c, int auxiliary, float final, unsigned level_of_state)
+{
+    fa_wfa *w = c->w;
+    unsigned s = w->states;
+    w->final_distribution[s] = final;
+    w->level_of_state[s] = (uint8_t) level_of_state;
+    if (!auxiliary) {
+        w->domain_type[s] = FA_USE_DOMAIN;
+        alloc_tables(c, s);
+        img_of(c, s)[0] = final;
+        compute_images(c, s, s);
+        compute_ip_states_state(c, s, s);
+    } else {
+        w->domain_type[s] = 0;
+        free(c->gram[s]); c->gram[s] = NULL;
+    }
+    w->states++;
+    if (w->states >= c->cp->limit_states) fail(c, "Maximum number of states reached!");
+}
+
+/* control.c:133-173 */
+static void append_basis_states(oc *c)
+{
+    fa_wfa *w = c->w;
+    unsigned s, n = w->basis_states;
+    for (s = 0; s < n; s++) {
+        alloc_tables(c, s);
+        img_of(c, s)[0] = w->final_distribution[s];
+        w->level_of_state[s] = (uint8_t) -1;
+    }
+    compute_images(c, 0, n - 1);
+    compute_ip_states_state(c, 0, n - 1);
+    w->states = n;
+}
+
+/* wfalib.c:152-180 */
+static float final_distribution(const fa_wfa *w, unsigned state)
+{
+    unsigned label, edge;
+    float f = 0;
+    int dom;
+    for (label = 0; label < 2; label++) {
+        if ((dom = FA_TREE(w, state, label)) != FA_RANGE) f += w->final_distribution[dom];
+        for (edge = 0; (dom = FA_INTO(w, state, label, edge)) != FA_NO_EDGE; edge++)
+            f += FA_WEIGHT(w, state, label, edge) * w->final_distribution[dom];
+    }
+    return f / 2;
+}
+
+static void remove_states(oc *c, unsigned from)
+{
+    unsigned s;
+    for (s = from; s < c->w->states; s++) { free(c->gram[s]); c->gram[s] = NULL; }
+    fa_wfa_remove_states(c->w, from);
+}
+
+/* ------------------------------------------------------------------ matching pursuit (codec/approx.c) */
+
+/* approx.c:644-699 */
+static void orthogonalize(oc *c, unsigned index, unsigned n, unsigned level, const int16_t *dl)
+{
+    const float min_norm = 2e-3f;
+    unsigned d, k;
+    c->ipio[n]    = c->rem_num[index];
+    c->norm_ov[n] = c->rem_den[index];
+    for (d = 0; dl[d] >= 0; d++) {
+        float t;
+        if (c->used[d]) continue;
+        t = ip_state_state(c, (unsigned) dl[index], (unsigned) dl[d], level);
+        for (k = 0; k < n; k++)
+            t -= c->ipdo[d * MAXED + k] / c->norm_ov[k] * c->ipdo[index * MAXED + k];
+        c->ipdo[d * MAXED + n] = t;
+        c->rem_den[d] -= t * t / c->norm_ov[n];
+        c->rem_num[d] -= c->ipio[n] / c->norm_ov[n] * c->ipdo[d * MAXED + n];
+        if (c->rem_den[d] / fa_size_of_level(level) < min_norm) c->used[d] = 1;
+    }
+}
+
+/* approx.c:317-642 (the <v_l,o_n> refresh :554-569 feeds only itself and is omitted,
+ * SURVEY §7.3 "dead code that looks live"; :570-571 are kept) */
+static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, unsigned max_edges,
+                             int y_state, const range *rg)
+{
+    const float min_norm = 2e-3f;
+    int16_t *dl = c->dlist;
+    unsigned n, d, best_n = 0, size = fa_size_of_level(rg->level);
+    int index;
+    float norm, additional_bits;
+
+    pool_generate(c, y_state, dl);
+    for (d = 0; dl[d] >= 0; d++) {
+        c->used[d] = 0;
+        c->rem_den[d] = ip_state_state(c, (unsigned) dl[d], (unsigned) dl[d], rg->level);
+        if (c->rem_den[d] / size < min_norm)
+            c->used[d] = 1;
+        else
+            c->rem_num[d] = ip_image_state(c, rg->image, rg->address, rg->level, (unsigned) dl[d]);
+        if (!c->used[d] && fabs(c->rem_num[d]) < min_norm) c->used[d] = 1;
+    }
+    for (n = 0; mp->exclude[n] != FA_NO_EDGE; n++) c->used[mp->exclude[n]] = 1;
+
+    for (norm = 0, n = 0; n < size; n++) {
+        float p = c->pixels[(size_t) rg->address * size + n];
+        norm += p * p;
+    }
+    additional_bits = rg->tree_bits;      /* mv / nd terms are zero without prediction */
+
+    mp->err = norm;
+    mp->weights_bits = 0;
+    mp->matrix_bits = pool_bits(c, dl, NULL, y_state);
+    mp->costs = (mp->matrix_bits + mp->weights_bits + additional_bits) * price + mp->err;
+
+    n = 0;
+    do {
+        float min_matrix_bits = 0, min_weights_bits = 0, min_error = 0, min_weight[MAXED];
+        float min_costs = full_search ? FA_MAXCOSTS : mp->costs;
+
+        for (index = -1, d = 0; dl[d] >= 0; d++) {
+            float matrix_bits, weights_bits;
+            if (c->used[d]) continue;
+            {   /* stage 1: price the candidate with placeholder weight 0.5 (:433-458) */
+                int16_t vectors[MAXED + 1], states[MAXED + 1];
+                float weights[MAXED + 1];
+                unsigned i = 0, k;
+                for (k = 0; k < n; k++)
+                    if (mp->weight[k] != 0) {
+                        vectors[i] = mp->indices[k];
+                        states[i]  = dl[vectors[i]];
+                        weights[i] = mp->weight[k];
+                        i++;
+                    }
+                vectors[i] = (int16_t) d; states[i] = dl[d]; weights[i] = 0.5f;
+                vectors[i + 1] = -1; states[i + 1] = -1;
+                weights_bits = coeff_bits(c, weights, states, rg->level);
+                matrix_bits  = pool_bits(c, dl, vectors, y_state);
+            }
+            if (((matrix_bits + weights_bits + additional_bits) * price + mp->err
+                 - c->rem_num[d] * c->rem_num[d] / c->rem_den[d]) < min_costs) {
+                unsigned k;
+                int l;
+                float m_bits, w_bits, r[MAXED], f[MAXED], costs, m_err;
+                int v[MAXED];
+
+                f[n] = c->rem_num[d] / c->rem_den[d];
+                v[n] = (int) d;
+                for (k = 0; k < n; k++) {
+                    f[k] = c->ipio[k] / c->norm_ov[k];
+                    v[k] = mp->indices[k];
+                }
+                for (l = (int) n; l >= 0; l--) {      /* back substitution, rounding each step */
+                    const fa_rpf *rpf = dl[v[l]] ? &c->cp->rpf : &c->cp->dc_rpf;
+                    r[l] = f[l] = quant(f[l], rpf);
+                    for (k = 0; k < (unsigned) l; k++)
+                        f[k] -= f[l] * c->ipdo[v[l] * MAXED + k] / c->norm_ov[k];
+                }
+                {
+                    int16_t vectors[MAXED + 1], states[MAXED + 1];
+                    float weights[MAXED + 1];
+                    unsigned i = 0;
+                    for (k = 0; k <= n; k++)
+                        if (f[k] != 0) {
+                            vectors[i] = (int16_t) v[k];
+                            states[i]  = dl[v[k]];
+                            weights[i] = f[k];
+                            i++;
+                        }
+                    vectors[i] = -1; states[i] = -1;
+                    w_bits = coeff_bits(c, weights, states, rg->level);
+                    m_bits = pool_bits(c, dl, vectors, y_state);
+                }
+                c->norm_ov[n] = c->rem_den[d];
+                c->ipio[n]    = c->rem_num[d];
+                for (k = 0; k <= n; k++)
+                    for (l = (int) k + 1; (unsigned) l <= n; l++)
+                        r[k] += c->ipdo[v[l] * MAXED + k] * r[l] / c->norm_ov[k];
+                m_err = norm;
+                for (k = 0; k <= n; k++)
+                    m_err += r[k] * r[k] * c->norm_ov[k] - 2 * r[k] * c->ipio[k];
+                costs = (m_bits + w_bits + additional_bits) * price + m_err;
+                if (costs < min_costs) {
+                    index = (int) d;
+                    min_costs = costs;
+                    min_matrix_bits = m_bits;
+                    min_weights_bits = w_bits;
+                    min_error = m_err;
+                    for (k = 0; k <= n; k++) min_weight[k] = f[k];
+                }
+            }
+        }
+        if (index >= 0) {
+            if (min_costs < mp->costs) {
+                unsigned k;
+                mp->costs = min_costs;
+                mp->err = min_error;
+                mp->matrix_bits = min_matrix_bits;
+                mp->weights_bits = min_weights_bits;
+                for (k = 0; k <= n; k++) mp->weight[k] = min_weight[k];
+                best_n = n + 1;
+            }
+            mp->indices[n] = (int16_t) index;
+            mp->into[n] = dl[index];
+            c->used[index] = 1;
+            orthogonalize(c, (unsigned) index, n, rg->level, dl);
+            n++;
+        }
+    } while (n < max_edges && index >= 0);
+
+    mp->indices[best_n] = FA_NO_EDGE;
+    mp->costs = (mp->matrix_bits + mp->weights_bits + additional_bits) * price + mp->err;
+}
+
+static int is_extreme(float wgt, const fa_rpf *rpf)
+{
+    return wgt == btor(fa_rtob(200, rpf), rpf) || wgt == btor(fa_rtob(-200, rpf), rpf);
+}
+
+/* approx.c:74-271 */
+static float approximate_range(oc *c, float max_costs, float price, unsigned max_edges,
+                               int y_state, range *rg)
+{
+    mpres mp;
+    memset(&mp, 0, sizeof mp);
+    mp.exclude[0] = FA_NO_EDGE;
+    matching_pursuit(c, &mp, c->cp->full_search, price, max_edges, y_state, rg);
+
+    if (c->cp->second_domain_block) {
+        mpres t = mp;
+        t.exclude[0] = t.indices[0];
+        t.exclude[1] = FA_NO_EDGE;
+        matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+        if (t.costs < mp.costs) mp = t;
+    }
+    if (c->cp->check_for_underflow) {
+        int it = -1;
+        mpres t = mp;
+        do {
+            int i;
+            it++;
+            t.exclude[it] = FA_NO_EDGE;
+            for (i = 0; t.indices[i] != FA_NO_EDGE; i++)
+                if (t.weight[i] == 0) { t.exclude[it] = t.indices[i]; break; }
+            if (t.exclude[it] != FA_NO_EDGE) {
+                t.exclude[it + 1] = FA_NO_EDGE;
+                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+                if (t.costs < mp.costs) mp = t;
+            }
+        } while (t.exclude[it] != FA_NO_EDGE && it < MAXED - 1);
+    }
+    if (c->cp->check_for_overflow) {
+        int it = -1;
+        mpres t = mp;
+        do {
+            int i;
+            it++;
+            t.exclude[it] = FA_NO_EDGE;
+            for (i = 0; t.indices[i] != FA_NO_EDGE; i++) {
+                const fa_rpf *rpf = t.indices[i] ? &c->cp->rpf : &c->cp->dc_rpf;
+                if (is_extreme(t.weight[i], rpf)) { t.exclude[it] = t.indices[i]; break; }
+            }
+            if (t.exclude[it] != FA_NO_EDGE) {
+                t.exclude[it + 1] = FA_NO_EDGE;
+                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+                if (t.costs < mp.costs) mp = t;
+            }
+        } while (t.exclude[it] != FA_NO_EDGE && it < MAXED - 1);
+    }
+
+    if (mp.costs < max_costs) {
+        int ni = 0, oi, e;
+        for (oi = 0; mp.indices[oi] != FA_NO_EDGE; oi++)
+            if (mp.weight[oi] != 0) {
+                mp.indices[ni] = mp.indices[oi];
+                mp.into[ni]    = mp.into[oi];
+                mp.weight[ni]  = mp.weight[oi];
+                ni++;
+            }
+        mp.indices[ni] = FA_NO_EDGE;
+        mp.into[ni]    = FA_NO_EDGE;
+        pool_generate(c, y_state, c->dlist);
+        pool_update(c, c->dlist, mp.indices, y_state);
+        coeff_update(c, mp.weight, mp.into, rg->level);
+        for (e = 0; mp.indices[e] != FA_NO_EDGE; e++) {
+            rg->into[e]   = mp.into[e];
+            rg->weight[e] = mp.weight[e];
+        }
+        rg->into[e] = FA_NO_EDGE;
+        rg->matrix_bits  = mp.matrix_bits;
+        rg->weights_bits = mp.weights_bits;
+        rg->err          = mp.err;
+    } else {
+        rg->into[0] = FA_NO_EDGE;
+        mp.costs = FA_MAXCOSTS;
+    }
+    return mp.costs;
+}
+
+/* ------------------------------------------------------------------ partition search (codec/subdivide.c) */
+
+/* subdivide.c:504-541: pixel/16 (C truncation), bintree (bit-interleaved) order */
+static void cut_to_bintree(float *dst, const int16_t *src, unsigned sw, unsigned sh,
+                           unsigned x0, unsigned y0, unsigned width, unsigned height)
+{
+    const unsigned mask01 = 0x555555, mask10 = 0xaaaaaa;
+    unsigned x, y, xm, ym = 0;
+    for (y = y0; y < y0 + height; y++, ym = (ym + mask10 + 1) & mask01) {
+        xm = 0;
+        for (x = x0; x < x0 + width; x++, xm = (xm + mask01 + 1) & mask10)
+            dst[xm | ym] = (y >= sh || x >= sw) ? 0 : (float) (src[y * sw + x] / 16);
+    }
+}
+
+/* subdivide.c:612-644 */
+static void init_range(oc *c, range *rg, unsigned band)
+{
+    unsigned s;
+    for (s = 0; s < c->w->states; s++)
+        if (need_image(c->w, s)) memset(ipis_of(c, s), 0, c->nprod * sizeof(float));
+    cut_to_bintree(c->pixels, c->im->pixels[band], c->im->width, c->im->height, rg->x, rg->y,
+                   fa_width_of_level(rg->level), fa_height_of_level(rg->level));
+    rg->address = rg->image = 0;
+    compute_ip_images_state(c, 0, 0, rg->level, 1, 0);
+}
+
+/* subdivide.c:549-610 */
+static void init_new_state(oc *c, int auxiliary, range *rg, const range *child, const int *y_state)
+{
+    fa_wfa *w = c->w;
+    unsigned label, s = w->states;
+    int is_domain = 0;
+    /* codec/subdivide.c:571-581: the state is offered to the rle pool (which may be full)
+     * and, because normal_domains is set, to the delta pool as well.  For I frames without
+     * prediction the delta pool is "constant", whose append() is default_append() == YES
+     * (domain-pool.c:957-962), so every non-auxiliary state keeps its image tables. */
+    if (!auxiliary) {
+        (void) pool_append(c, s);
+        is_domain = 1;
+    }
+    rg->into[0] = FA_NO_EDGE;
+    rg->tree = (int) s;
+    for (label = 0; label < 2; label++) {
+        unsigned e;
+        FA_TREE(w, s, label) = (int16_t) child[label].tree;
+        w->y_state[s * 2 + label] = (int16_t) y_state[label];
+        w->x[s * 2 + label] = (uint16_t) child[label].x;
+        w->y[s * 2 + label] = (uint16_t) child[label].y;
+        w->prediction[s * 2 + label] = 0;
+        w->y_column[s * 2 + label] = 0;
+        for (e = 0; child[label].into[e] != FA_NO_EDGE; e++) {
+            fa_wfa_append_edge(w, s, (unsigned) child[label].into[e], child[label].weight[e], label);
+            if (child[label].into[e] == w->y_state[s * 2 + label]) w->y_column[s * 2 + label] = 1;
+        }
+    }
+    w->delta_state[s] = 0;
+    append_state(c, !is_domain, final_distribution(w, s), rg->level);
+}
+
+static float fminf2(float a, float b) { return a > b ? b : a; }
+
+/* subdivide.c:60-502 without the prediction branch */
+static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range *rg)
+{
+    fa_wfa *w = c->w;
+    float subdivide_costs, lincomb_costs, price;
+    int new_y_state[2];
+    unsigned states, label;
+    rle_model pool0, pool_lc;
+    int16_t *coeff0, *coeff_lc, *ct0, *ct_lc;
+    unsigned *tm0;
+    range lrange, rrange, child[2];
+    size_t csz = c->coeff_size * sizeof(int16_t), tsz = c->coeff_nt * sizeof(int16_t);
+    size_t tmsz = (size_t) 4 * c->ML * sizeof(unsigned);
+
+    if (c->failed) return FA_MAXCOSTS;
+    rg->into[0] = FA_NO_EDGE;
+    rg->tree = FA_RANGE;
+    if (rg->level < 3) return FA_MAXCOSTS;
+    if (rg->x >= c->im->width || rg->y >= c->im->height) return 0;   /* not visible */
+
+    if (rg->level == c->lc_max) init_range(c, rg, band);
+
+    price = c->price;
+    if (band != FA_Y) price *= c->cp->chroma_decrease;
+    if (band != FA_Y)
+        for (label = 0; label < 2; label++)
+            new_y_state[label] = y_state != FA_RANGE ? FA_TREE(w, y_state, label) : FA_RANGE;
+    else
+        new_y_state[0] = new_y_state[1] = FA_RANGE;
+
+    /* snapshot every model the recursion may touch */
+    pool0 = c->pool;
+    coeff0 = (int16_t *) malloc(csz); ct0 = (int16_t *) malloc(tsz);
+    coeff_lc = (int16_t *) malloc(csz); ct_lc = (int16_t *) malloc(tsz);
+    tm0 = (unsigned *) malloc(tmsz);
+    memcpy(coeff0, c->coeff, csz); memcpy(ct0, c->coeff_totals, tsz);
+    memcpy(tm0, c->tm, tmsz);
+    states = w->states;
+
+    if (rg->level <= c->lc_max) {
+        lrange = *rg;
+        lrange.tree = FA_RANGE;
+        lrange.tree_bits = tree_bits(c, 0, lrange.level, 0);
+        lrange.matrix_bits = 0;
+        lrange.weights_bits = 0;
+        lincomb_costs = approximate_range(c, max_costs, price, c->max_elements, y_state, &lrange);
+    } else
+        lincomb_costs = FA_MAXCOSTS;
+
+    /* keep the models as modified by the linear combination, continue from the snapshot */
+    pool_lc = c->pool;
+    memcpy(coeff_lc, c->coeff, csz); memcpy(ct_lc, c->coeff_totals, tsz);
+    c->pool = pool0;
+    memcpy(c->coeff, coeff0, csz); memcpy(c->coeff_totals, ct0, tsz);
+
+    if (rg->level > c->lc_min) {
+        memset(child, 0, sizeof child);
+        rrange = *rg;
+        rrange.tree_bits = tree_bits(c, 1, rrange.level, 0);
+        rrange.matrix_bits = 0;
+        rrange.weights_bits = 0;
+        rrange.err = 0;
+        subdivide_costs = (rrange.tree_bits + rrange.weights_bits + rrange.matrix_bits) * price;
+
+        for (label = 0; label < 2; label++) {
+            float remaining;
+            child[label].image = rrange.image * 2 + label + 1;
+            child[label].address = rrange.address * 2 + label;
+            child[label].global_address = rrange.global_address * 2 + label;
+            child[label].level = rrange.level - 1;
+            child[label].x = (rrange.level & 1) ? rrange.x
+                             : rrange.x + label * fa_width_of_level(rrange.level - 1);
+            child[label].y = (rrange.level & 1)
+                             ? rrange.y + label * fa_height_of_level(rrange.level - 1) : rrange.y;
+            if (label && rrange.level <= c->lc_max)
+                compute_ip_images_state(c, child[label].image, child[label].address,
+                                        child[label].level, 1, states);
+            remaining = fminf2(lincomb_costs, max_costs) - subdivide_costs;
+            if (remaining > 0)
+                subdivide_costs += subdivide(c, remaining, band, new_y_state[label], &child[label]);
+            if (subdivide_costs >= fminf2(lincomb_costs, max_costs)) {
+                subdivide_costs = FA_MAXCOSTS;
+                break;
+            }
+            rrange.err          += child[label].err;
+            rrange.tree_bits    += child[label].tree_bits;
+            rrange.matrix_bits  += child[label].matrix_bits;
+            rrange.weights_bits += child[label].weights_bits;
+            tree_update(c, child[label].tree != FA_RANGE, child[label].level, 0);
+            tree_update(c, 1, child[label].level, 1);   /* child.prediction is NO -> CHILD */
+        }
+    } else
+        subdivide_costs = FA_MAXCOSTS;
+
+    if (lincomb_costs >= FA_MAXCOSTS && subdivide_costs >= FA_MAXCOSTS) {
+        c->pool = pool0;
+        memcpy(c->coeff, coeff0, csz); memcpy(c->coeff_totals, ct0, tsz);
+        memcpy(c->tm, tm0, tmsz);
+        if (w->states != states) remove_states(c, states);
+        subdivide_costs = FA_MAXCOSTS;
+    } else if (lincomb_costs < subdivide_costs) {
+        c->pool = pool_lc;
+        memcpy(c->coeff, coeff_lc, csz); memcpy(c->coeff_totals, ct_lc, tsz);
+        memcpy(c->tm, tm0, tmsz);
+        *rg = lrange;
+        if (w->states != states) remove_states(c, states);
+        subdivide_costs = lincomb_costs;
+    } else {
+        int aux = band > FA_Y
+                  || rg->x + fa_width_of_level(rg->level) > c->im->width
+                  || rg->y + fa_height_of_level(rg->level) > c->im->height;
+        init_new_state(c, aux, &rrange, child, new_y_state);
+        *rg = rrange;
+    }
+    free(coeff0); free(ct0); free(coeff_lc); free(ct_lc); free(tm0);
+    return subdivide_costs;
+}
+
+/* ------------------------------------------------------------------ frame (codec/coder.c:692-892) */
+
+static void root_range(range *rg, unsigned level)
+{
+    memset(rg, 0, sizeof *rg);
+    rg->level = level;
+}
+
+static void put_stats(fa_stats *st, float costs, const range *rg)
+{
+    st->costs = costs; st->err = rg->err; st->tree_bits = rg->tree_bits;
+    st->matrix_bits = rg->matrix_bits; st->weights_bits = rg->weights_bits;
+}
+
+static int encode_one(fa_job *job)
+{
+    oc c;
+    fa_wfa *w = job->wfa;
+    const fa_cparams *cp = &job->cp;
+    unsigned cap = cp->limit_states, s;
+    range rg;
+    float costs;
+
+    memset(&c, 0, sizeof c);
+    c.cp = cp; c.im = job->image; c.w = w;
+    c.lc_min = cp->lc_min_level; c.lc_max = cp->lc_max_level;
+    c.images_level = cp->images_level; c.products_level = cp->products_level;
+    c.max_elements = cp->max_elements;
+    c.price = cp->price;
+    c.nimg = fa_size_of_tree(c.images_level);
+    c.nprod = fa_size_of_tree(c.products_level);
+    c.nlev = c.lc_max - c.images_level;
+    c.ML = cp->limit_level;
+    c.images = (float *) calloc((size_t) cap * c.nimg, sizeof(float));
+    c.ipis = (float *) calloc((size_t) cap * c.nprod, sizeof(float));
+    c.gram = (float **) calloc(cap, sizeof(float *));
+    c.pixels = (float *) calloc(fa_size_of_level(c.lc_max), sizeof(float));
+    c.tm = (unsigned *) calloc((size_t) 4 * c.ML + 4, sizeof(unsigned));
+    c.pool_states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
+    c.rem_num = (float *) calloc(cap + 2, sizeof(float));
+    c.rem_den = (float *) calloc(cap + 2, sizeof(float));
+    c.ipdo = (float *) calloc((size_t) (cap + 2) * MAXED, sizeof(float));
+    c.used = (uint8_t *) calloc(cap + 2, 1);
+    c.dlist = (int16_t *) calloc(cap + 4, sizeof(int16_t));
+    init_matrix_tables(&c);
+
+    append_basis_states(&c);
+    tree_init(c.tm, c.tm + c.ML, c.ML);
+    tree_init(c.tm + 2 * c.ML, c.tm + 3 * c.ML, c.ML);
+    pool_init(&c);
+    coeff_init(&c);
+
+    if (!job->image->color) {
+        root_range(&rg, cp->level);
+        costs = subdivide(&c, FA_MAXCOSTS, FA_GRAY, FA_RANGE, &rg);
+        put_stats(&job->stats[0], costs, &rg);
+        if (!c.failed && rg.tree == FA_RANGE) fail(&c, "No root state generated!");
+        else w->root_state = (unsigned) rg.tree;
+    } else {
+        int tree[3] = { FA_RANGE, FA_RANGE, FA_RANGE }, ycb = -1;
+        unsigned band;
+        for (band = FA_Y; band <= FA_CR && !c.failed; band++) {
+            if (band == FA_CB) {
+                unsigned min_level = c.ML;    /* MAXLEVEL, codec/coder.c:785 */
+                pool_chroma(&c);
+                for (s = w->basis_states; s < w->states; s++) {
+                    unsigned lin = (FA_TREE(w, s, 0) == FA_RANGE) + (FA_TREE(w, s, 1) == FA_RANGE);
+                    if (lin && (unsigned) (w->level_of_state[s] - 1) < min_level)
+                        min_level = (unsigned) (w->level_of_state[s] - 1);
+                }
+                c.lc_min = min_level;
+            }
+            root_range(&rg, cp->level);
+            costs = subdivide(&c, FA_MAXCOSTS, band, tree[FA_Y], &rg);
+            put_stats(&job->stats[band], costs, &rg);
+            if (c.failed) break;
+            if (rg.tree == FA_RANGE) { fail(&c, "No root state generated for color component!"); break; }
+            tree[band] = rg.tree;
+            if (band == FA_CB) {
+                FA_TREE(w, w->states, 0) = (int16_t) tree[FA_Y];
+                FA_TREE(w, w->states, 1) = (int16_t) tree[FA_CB];
+                ycb = (int) w->states;
+                append_state(&c, 1, final_distribution(w, w->states), cp->level + 1);
+            }
+        }
+        if (!c.failed) {
+            FA_TREE(w, w->states, 0) = (int16_t) tree[FA_CR];
+            FA_TREE(w, w->states, 1) = FA_RANGE;
+            append_state(&c, 1, final_distribution(w, w->states), cp->level + 1);
+            FA_TREE(w, w->states, 0) = (int16_t) ycb;
+            FA_TREE(w, w->states, 1) = (int16_t) (w->states - 1);
+            append_state(&c, 1, final_distribution(w, w->states), cp->level + 2);
+            w->root_state = w->states - 1;
+        }
+    }
+    job->lc_min_level_out = c.lc_min;
+    job->status = !c.failed;
+    if (c.failed) snprintf(job->errmsg, sizeof job->errmsg, "%s", c.err);
+
+    for (s = 0; s < cap; s++) free(c.gram[s]);
+    free(c.images); free(c.ipis); free(c.gram); free(c.pixels); free(c.tm); free(c.pool_states);
+    free(c.rem_num); free(c.rem_den); free(c.ipdo); free(c.used); free(c.dlist);
+    free(c.coeff); free(c.coeff_totals);
+    return job->status;
+}
+
+int fa_core_encode_frames(unsigned n, fa_job *jobs)
+{
+    unsigned i;
+    int good = 0;
+    for (i = 0; i < n; i++) good += encode_one(&jobs[i]);
+    return good;
+}
+
+const char *fa_core_name(void) { return "oracle-cpu"; }

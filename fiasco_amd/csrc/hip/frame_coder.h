@@ -1,0 +1,75 @@
+/*
+ *  frame_coder.h -- device-side data layout of the MI355X frame coder (shared between the
+ *  kernel and its host launcher).  One persistent workgroup encodes one frame; all tables
+ *  of that frame live in one HBM slab described by DevFrame.
+ *
+ *  HBM layout per frame (P = pitch = state capacity rounded up to 64):
+ *    gram   [NL][P][P] f32  symmetric <state,state> tables, level images_level..lc_max
+ *                           (reference ip_states_state, codec/cwfa.h:86, is lower
+ *                           triangular per level; stored full so that both the
+ *                           Gram-Schmidt row sweep and the row append read contiguous rows)
+ *    diag   [NL][P]    f32  Gram diagonal (matching-pursuit denominators)
+ *    ipis   [NS][P]    f32  <range sub-block, state>, heap slot major
+ *                           (reference ip_images_state, codec/cwfa.h:89, is state major)
+ *    d5     [NA][P]    f32  level-images_level dots of the current block, address major
+ *    img    [P][NI]    f32  state images levels 0..images_level (reference layout)
+ *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
+ *    num/den/est [P], ipdo [MAXED][P], used [P]   matching-pursuit scratch
+ *    tree [2][P] i16, into [2][6][P] i16, weight [2][6][P] f32, ...  automaton, SoA
+ */
+#ifndef FRAME_CODER_H
+#define FRAME_CODER_H
+#include <stdint.h>
+
+#define FC_MAXED   5
+#define FC_BLOCK   256          /* threads per frame workgroup */
+#define FC_MAXDEPTH 22          /* recursion depth bound: level <= 26, lc_min >= 6 */
+#define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS */
+#define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
+
+enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5 };
+
+struct FcTrace;
+typedef struct DevFrame {
+    /* ---- parameters ---- */
+    float    price;
+    int      lc_min, lc_max, images_level, max_elements;
+    int      level, width, height;
+    int      pool_max, limit_states, ML;
+    int      rpf_mant, dc_mant;
+    float    rpf_range, dc_range;
+    int      P;            /* pitch / state capacity */
+    int      NL, NS, NA, NI;
+    int      coeff_size, coeff_nt, dcs, sy;
+    int      basis_states;
+    /* ---- tables ---- */
+    const int16_t *pix16;
+    float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;
+    float   *num, *den, *est, *ipdo;
+    uint8_t *used;
+    int16_t *tree, *into;
+    float   *weight, *final_d;
+    uint8_t *level_of_state, *domain_type;
+    uint16_t *x, *y;
+    int16_t *pool_states;
+    /* ---- results ---- */
+    int      status;
+    int      states, root_state;
+    float    costs, err, tree_bits, matrix_bits, weights_bits;
+    /* ---- counters for the roofline model ---- */
+    unsigned long long bytes_mp, bytes_img, bytes_gram;
+    unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
+    /* ---- optional per-call trace (FIASCO_AMD_TRACE), compared with the oracle's ---- */
+    struct FcTrace *trace;
+    int      trace_cap, trace_n;
+} DevFrame;
+
+/* one record per approximate_range call; identical layout in oracle/oracle_core.c */
+typedef struct FcTrace {
+    int   seq, level, image, D, states, nedges;
+    float cost, err, mbits, wbits;
+    short into[6];
+    float w[5];
+} FcTrace;
+
+#endif

@@ -1,0 +1,1045 @@
+/*
+ *  frame_coder.hip -- the FIASCO encode-side hot path as ONE persistent gfx950 kernel:
+ *  one 256-thread workgroup owns one frame and runs its complete partition search.
+ *
+ *  What runs here (reference file:line it is bit-compatible with):
+ *    partition search        codec/subdivide.c:60-502   (serial state machine, lane 0,
+ *                                                         explicit LDS stack)
+ *    init_range              codec/subdivide.c:504-541,612-644
+ *    matching pursuit        codec/approx.c:74-271,317-699 (domain-parallel, see below)
+ *    inner-product tables    codec/ip.c:46-323
+ *    state tables            codec/control.c:48-131,205-258
+ *    rle pool / aac / tree   codec/domain-pool.c:621-852, codec/coeff.c:215-267,
+ *    rate models             codec/bintree.c:35-73, lib/rpf.c:59-169, lib/misc.c:223-244
+ *
+ *  Parallel decomposition of one matching-pursuit call (D candidate domains):
+ *    phase A (all waves)  per candidate d, fused: Gram-Schmidt update of rem_num/rem_den
+ *                         against the vector chosen in the previous step + stage-1 cost
+ *                         estimate e_d; wave-wide min of e_d per 64-candidate block.
+ *    phase B (wave 0)     exact replay of the reference's index-ordered scan with its
+ *                         running `min_costs`: blocks whose min e_d cannot beat the
+ *                         running minimum are skipped; inside a block the survivors'
+ *                         true costs are evaluated lane-parallel and accepted in index
+ *                         order by ballot/ffs (strict '<', as codec/approx.c:459-462,592).
+ *  All float arithmetic keeps the reference's operation order; this file MUST be built
+ *  with -ffp-contract=off (no FMA).  double log2() is evaluated once per call into small
+ *  LDS tables (the rate models only ever need log2 of count/total ratios).
+ *
+ *  Device scope of this build: grayscale I frames, `rle` pool, `adaptive` coefficients,
+ *  optimisation level 0, lc_min_level > images_level == 5 (CLI defaults).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "frame_coder.h"
+
+#define B       FC_BLOCK
+#define MAXED   FC_MAXED
+#define NOEDGE  (-1)
+#define RANGE_  (-1)
+#define MAXCOSTS 1e20f
+#define BIGF    3.0e38f
+#define MIN_NORM 2e-3f
+
+enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND };
+enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
+       PH_AFTER_APPEND };
+
+struct Range {
+    int   x, y, image, address, level, tree;
+    float weight[MAXED + 1];
+    short into[MAXED + 1];
+    float err, tree_bits, matrix_bits, weights_bits;
+};
+
+struct Pool {                    /* rle model, codec/domain-pool.c:621-630 */
+    short count[MAXED + 1];
+    unsigned short total, n, max_domains, y_index;
+    short d0_index;
+    unsigned short d0_yindex, d0_n;
+};
+
+struct SFrame {
+    Range rg, lrange, rrange, child[2];
+    Pool  pool0, pool_lc;
+    float max_costs, lincomb, subdiv, ret, price;
+    int   label, states, phase;
+};
+
+struct MPState {
+    int   n, best_n, index, D, N, level, image, address, row_state;
+    short indices[MAXED + 1], into[MAXED + 1];
+    float weight[MAXED];
+    float matrix_bits, weights_bits, err, costs, min_costs;
+    float sel_ipdo[MAXED][MAXED];
+    float norm_ov[MAXED + 1], ipio[MAXED + 1];
+    short psorted[MAXED + 1];
+    int   np;
+    float wb_dc, wb_nd, norm, ab, price, max_costs;
+    /* best candidate of the running step */
+    float b_cost, b_mbits, b_wbits, b_err, b_f[MAXED];
+    int   b_index;
+};
+
+struct Sh {
+    SFrame   st[FC_MAXDEPTH];
+    int      sp;
+    int      op, a0, a1, a2, a3;
+    Pool     pool;
+    short    coeff[FC_MAXCOEFF];
+    short    coeff_tot[32];
+    short    snap_coeff[FC_MAXDEPTH][2][FC_MAXCOEFF + 32];
+    unsigned tm[4 * 26 + 8];
+    unsigned snap_tm[FC_MAXDEPTH][4 * 26];
+    float    m0tab[12];
+    double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM];
+    float    Ltab[MAXED + 1];
+    float    Q0, Q1;
+    MPState  mp;
+    float    blockmin[512];
+    float    pixels[1024];
+    int      states;               /* wfa->states */
+    int      failed;
+};
+
+/* ------------------------------------------------------------------ small helpers */
+
+__device__ __forceinline__ unsigned width_of_level(int l)  { return 1u << (l >> 1); }
+__device__ __forceinline__ unsigned height_of_level(int l) { return 1u << ((l + 1) >> 1); }
+
+/* lib/rpf.c:59-112 (x86 masks variable shift counts to 5 bits; so does this) */
+__device__ int rtob_dev(float f, int mant, float range)
+{
+    f /= range;
+    unsigned bits = __float_as_uint(f);
+    unsigned m = bits & 0x7fffffu;
+    int e = (int) ((bits >> 23) & 0xffu) - 126;
+    int sign = (int) (bits >> 31);
+    m = (m >> 1) | (1u << 22);
+    if (e > 0) m <<= ((unsigned) e & 31u);
+    else       m >>= ((unsigned) (-e) & 31u);
+    m >>= (23 - mant - 1);
+    m += 1;
+    m >>= 1;
+    if (m == 0) return -1;
+    if (m >= (1u << mant)) return sign;
+    return (int) (((m & ((1u << mant) - 1)) << 1) | (unsigned) sign);
+}
+
+/* lib/rpf.c:114-169 */
+__device__ float btor_dev(int b, int mant, float range)
+{
+    if (b == -1) return 0.0f;
+    int sign = b & 1;
+    unsigned m = ((unsigned) b & ((1u << (mant + 1)) - 1)) >> 1;
+    m <<= (23 - mant);
+    float v;
+    if (m == 0)
+        v = sign ? -1.0f : 1.0f;
+    else {
+        int e = 0;
+        while (!(m & (1u << 22))) { e--; m <<= 1; }
+        m <<= 1;
+        v = __uint_as_float(((unsigned) sign << 31) | ((unsigned) (e + 126) << 23) | (m & 0x7fffffu));
+    }
+    return v * range;
+}
+
+/* lib/misc.c:223-244 */
+__device__ __forceinline__ unsigned bits_bin_code(unsigned value, unsigned maxval)
+{
+    unsigned k = 31u - (unsigned) __clz((int) (maxval + 1));
+    unsigned r = (maxval + 1) - (1u << k);
+    return value < maxval + 1 - 2 * r ? k : k + 1;
+}
+
+/* probability index -> shift n of the quasi-arithmetic model (domain-pool.c:970-999) */
+__device__ __forceinline__ int qac_shift(int index)
+{
+    int n = 1, start = 0;
+    while (index >= start + (1 << n)) { start += 1 << n; n++; }
+    return n;
+}
+
+/* rle_bits (domain-pool.c:737-793) for an ascending list of non-y positions */
+__device__ float pool_bits_sorted(const short *sorted, int nn, const Sh &sh)
+{
+    float bits = sh.Ltab[nn];
+    bits += (nn && sorted[0] == 0) ? sh.Q1 : sh.Q0;
+    unsigned last = 1, N = (unsigned) sh.mp.N;
+    for (int e = 0; e < nn; e++) {
+        int into = sorted[e];
+        if (into && (N - 1 - last)) {
+            bits += (float) bits_bin_code((unsigned) into - last, N - 1 - last);
+            last = (unsigned) into + 1;
+        }
+    }
+    return bits;
+}
+
+/* ------------------------------------------------------------------ table access */
+
+#define GRAM(F, q)   ((F).gram + (size_t) (q) * (F).P * (F).P)
+#define TREE(F, s, l)        ((F).tree[(l) * (F).P + (s)])
+#define INTO(F, s, l, e)     ((F).into[((l) * 6 + (e)) * (F).P + (s)])
+#define WEIGHT(F, s, l, e)   ((F).weight[((l) * 6 + (e)) * (F).P + (s)])
+
+/* one Gram entry at table level q >= 1 from level q-1 (codec/ip.c:213-257) */
+__device__ float gram_entry(const DevFrame &F, int q, int s1, int s2)
+{
+    const float *G = GRAM(F, q - 1);
+    const size_t P = (size_t) F.P;
+    float ip = 0;
+    for (int label = 0; label < 2; label++) {
+        int d1, d2;
+        float sum;
+        int t2 = TREE(F, s2, label);
+        if ((d1 = TREE(F, s1, label)) != RANGE_) {
+            sum = 0;
+            if (t2 != RANGE_) sum = G[(size_t) d1 * P + t2];
+            for (int e2 = 0; (d2 = INTO(F, s2, label, e2)) != NOEDGE; e2++)
+                sum += WEIGHT(F, s2, label, e2) * G[(size_t) d1 * P + d2];
+            ip += sum;
+        }
+        for (int e1 = 0; (d1 = INTO(F, s1, label, e1)) != NOEDGE; e1++) {
+            float w1 = WEIGHT(F, s1, label, e1);
+            sum = 0;
+            if (t2 != RANGE_) sum = G[(size_t) d1 * P + t2];
+            for (int e2 = 0; (d2 = INTO(F, s2, label, e2)) != NOEDGE; e2++)
+                sum += WEIGHT(F, s2, label, e2) * G[(size_t) d1 * P + d2];
+            ip += w1 * sum;
+        }
+    }
+    return ip;
+}
+
+/* level-images_level Gram entry: plain sequential dot (codec/ip.c:297-323) */
+__device__ float gram_dot(const DevFrame &F, int s1, int s2)
+{
+    const int n = 1 << F.images_level;
+    float ip = 0;
+    for (int k = 0; k < n; k++)
+        ip += F.imgT[(size_t) k * F.P + s1] * F.imgT[(size_t) k * F.P + s2];
+    return ip;
+}
+
+__device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
+{
+    float *G = GRAM(F, q);
+    G[(size_t) s * F.P + t] = v;
+    G[(size_t) t * F.P + s] = v;
+    if (s == t) F.diag[(size_t) q * F.P + s] = v;
+}
+
+/* state image element (codec/control.c:205-258): level l >= 1, position i */
+__device__ float image_elem(const DevFrame &F, int s, int l, int i)
+{
+    int half = 1 << (l - 1);
+    int label = i >= half;
+    int pos = i - label * half;
+    int base = half - 1;                 /* address_of_level(l-1) */
+    float v = 0;
+    int dom;
+    if ((dom = TREE(F, s, label)) != RANGE_) v = F.img[(size_t) dom * F.NI + base + pos];
+    for (int e = 0; (dom = INTO(F, s, label, e)) != NOEDGE; e++)
+        v += F.img[(size_t) dom * F.NI + base + pos] * WEIGHT(F, s, label, e);
+    return v;
+}
+
+/* ------------------------------------------------------------------ parallel ops */
+
+/* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
+ * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
+ * onto zero, which is the reference's accumulation order onto its zeroed slots. */
+__device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
+{
+    const int tid = threadIdx.x, il = F.images_level, P = F.P, states = sh.states;
+    for (int lv = il + 1; lv <= level; lv++) {
+        int delta = level - lv;
+        int cnt = 1 << delta;
+        int slot0 = ((image + 1) << delta) - 1;
+        int adr0 = address << delta;
+        for (int s = from + tid; s < states; s += B) {
+            if (!F.domain_type[s]) continue;
+            int kid[2], ne[2], ed[2][MAXED + 1];
+            float ew[2][MAXED + 1];
+            for (int l = 0; l < 2; l++) {
+                kid[l] = TREE(F, s, l);
+                int e = 0, d;
+                for (; (d = INTO(F, s, l, e)) != NOEDGE; e++) { ed[l][e] = d; ew[l][e] = WEIGHT(F, s, l, e); }
+                ne[l] = e;
+            }
+            for (int j = 0; j < cnt; j++) {
+                float acc = 0;
+                for (int l = 0; l < 2; l++) {
+                    const float *src = (lv == il + 1)
+                        ? F.d5 + (size_t) ((adr0 + j) * 2 + l) * P
+                        : F.ipis + (size_t) ((slot0 + j) * 2 + l + 1) * P;
+                    if (kid[l] != RANGE_) acc += src[kid[l]];
+                    for (int e = 0; e < ne[l]; e++) {
+                        if (lv == il + 1) acc += ew[l][e] * src[ed[l][e]];
+                        else              acc += src[ed[l][e]] * ew[l][e];
+                    }
+                }
+                F.ipis[(size_t) (slot0 + j) * P + s] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+/* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
+__device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
+{
+    const int tid = threadIdx.x, P = F.P;
+    for (int s = from + tid; s < to; s += B) {
+        if (!F.domain_type[s]) continue;
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = F.imgT[(size_t) k * P + s];
+        for (int a = 0; a < F.NA; a++) {
+            float ip = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * v[k];
+            F.d5[(size_t) a * P + s] = ip;
+        }
+    }
+}
+
+/* codec/subdivide.c:504-541,612-644 */
+__device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
+{
+    const int tid = threadIdx.x;
+    const int level = F.lc_max, npx = 1 << level;
+    for (int i = tid; i < npx; i += B) {
+        unsigned xo = 0, yo = 0;
+        for (int b = 0; b < 13; b++) {
+            yo |= ((i >> (2 * b)) & 1u) << b;         /* even bits: rows (mask 0x555555)   */
+            xo |= ((i >> (2 * b + 1)) & 1u) << b;     /* odd bits: columns (mask 0xaaaaaa) */
+        }
+        int x = x0 + (int) xo, y = y0 + (int) yo;
+        float v = 0;
+        if (y < F.height && x < F.width) v = (float) (F.pix16[(size_t) y * F.width + x] / 16);
+        sh.pixels[i] = v;
+    }
+    __syncthreads();
+    /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
+    for (int slot = tid; slot < F.NS; slot += B) {
+        int depth = 31 - __clz(slot + 1);
+        int lv = level - depth, size = 1 << lv;
+        int adr = slot + 1 - (1 << depth);
+        float nrm = 0;
+        for (int k = 0; k < size; k++) { float p = sh.pixels[adr * size + k]; nrm += p * p; }
+        F.norms[slot] = nrm;
+    }
+    op_d5(F, sh, 0, sh.states);
+    __syncthreads();
+    op_ipis(F, sh, 0, 0, level, 0);
+    if (tid == 0) {
+        F.bytes_img += (unsigned long long) sh.states * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
+        F.n_blocks++;
+    }
+}
+
+/* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
+__device__ void op_append(DevFrame &F, Sh &sh, int s)
+{
+    const int tid = threadIdx.x, il = F.images_level, P = F.P;
+    /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
+     * depends on level l-1 of OTHER states only */
+    if (tid == B - 1) F.img[(size_t) s * F.NI] = F.final_d[s];
+    for (int i = tid; i < F.NI - 1; i += B) {
+        int l = 31 - __clz(i + 2);                      /* offset 2^l - 1 + pos = i + 1 */
+        int pos = i + 1 - ((1 << l) - 1);
+        float v = image_elem(F, s, l, pos);
+        F.img[(size_t) s * F.NI + i + 1] = v;
+        if (l == il) F.imgT[(size_t) pos * P + s] = v;
+    }
+    __syncthreads();
+    /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
+    for (int t = tid; t <= s; t += B) {
+        if (!F.domain_type[t]) continue;
+        gram_store(F, 0, s, t, gram_dot(F, s, t));
+        for (int q = 1; q < F.NL; q++) gram_store(F, q, s, t, gram_entry(F, q, s, t));
+    }
+    for (int a = tid; a < F.NA; a += B) {
+        float ip = 0;
+        for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * F.imgT[(size_t) k * P + s];
+        F.d5[(size_t) a * P + s] = ip;
+    }
+    if (tid == 0) {
+        int E = 0;
+        for (int l = 0; l < 2; l++) {
+            if (TREE(F, s, l) != RANGE_) E++;
+            for (int e = 0; INTO(F, s, l, e) != NOEDGE; e++) E++;
+        }
+        F.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
+        F.n_appends++;
+    }
+}
+
+/* ---- matching pursuit ---------------------------------------------------------- */
+
+/* stage-1 estimate of candidate position d (codec/approx.c:433-462) */
+__device__ __forceinline__ float stage1(const Sh &sh, int d, int state, float num, float den)
+{
+    const MPState &mp = sh.mp;
+    short merged[MAXED + 1];
+    int nn = 0, placed = 0;
+    for (int i = 0; i < mp.np; i++) {
+        if (!placed && d < mp.psorted[i]) { merged[nn++] = (short) d; placed = 1; }
+        merged[nn++] = mp.psorted[i];
+    }
+    if (!placed) merged[nn++] = (short) d;
+    float matrix_bits = pool_bits_sorted(merged, nn, sh);
+    float weights_bits = state ? mp.wb_nd : mp.wb_dc;
+    return (matrix_bits + weights_bits + mp.ab) * mp.price + mp.err - num * num / den;
+}
+
+struct Eval { float costs, m_bits, w_bits, m_err, f[MAXED]; };
+
+/* full evaluation of candidate d (codec/approx.c:495-591 without the dead :554-569) */
+__device__ void full_eval(const DevFrame &F, const Sh &sh, int d, int state, float num, float den,
+                          Eval &ev)
+{
+    const MPState &mp = sh.mp;
+    const int n = mp.n, P = F.P;
+    float f[MAXED], r[MAXED], ipd[MAXED][MAXED], nov[MAXED + 1], ipio[MAXED + 1];
+    int   v[MAXED], st[MAXED];
+    for (int k = 0; k < n; k++) {
+        nov[k] = mp.norm_ov[k]; ipio[k] = mp.ipio[k];
+        f[k] = ipio[k] / nov[k];
+        v[k] = mp.indices[k]; st[k] = mp.into[k];
+        for (int j = 0; j < k; j++) ipd[k][j] = mp.sel_ipdo[k][j];
+    }
+    f[n] = num / den; v[n] = d; st[n] = state;
+    for (int j = 0; j < n; j++) ipd[n][j] = F.ipdo[(size_t) j * P + d];
+    for (int l = n; l >= 0; l--) {
+        int mant = st[l] ? F.rpf_mant : F.dc_mant;
+        float range = st[l] ? F.rpf_range : F.dc_range;
+        r[l] = f[l] = btor_dev(rtob_dev(f[l], mant, range), mant, range);
+        for (int k = 0; k < l; k++) f[k] -= f[l] * ipd[l][k] / nov[k];
+    }
+    {   /* rate of the rounded combination */
+        short sorted[MAXED + 1];
+        int nn = 0;
+        float wb = 0;
+        for (int k = 0; k <= n; k++)
+            if (f[k] != 0) {
+                if (st[k]) wb = (float) ((double) wb - sh.lglv[rtob_dev(f[k], F.rpf_mant, F.rpf_range)]);
+                else       wb = (float) ((double) wb - sh.lgdc[rtob_dev(f[k], F.dc_mant, F.dc_range)]);
+                int j = nn++;
+                while (j > 0 && sorted[j - 1] > v[k]) { sorted[j] = sorted[j - 1]; j--; }
+                sorted[j] = (short) v[k];
+            }
+        ev.w_bits = wb;
+        ev.m_bits = pool_bits_sorted(sorted, nn, sh);
+    }
+    nov[n] = den; ipio[n] = num;
+    for (int k = 0; k <= n; k++)
+        for (int l = k + 1; l <= n; l++) r[k] += ipd[l][k] * r[l] / nov[k];
+    float m_err = mp.norm;
+    for (int k = 0; k <= n; k++) m_err += r[k] * r[k] * nov[k] - 2 * r[k] * ipio[k];
+    ev.m_err = m_err;
+    ev.costs = (ev.m_bits + ev.w_bits + mp.ab) * mp.price + m_err;
+    for (int k = 0; k <= n; k++) ev.f[k] = f[k];
+}
+
+/* log2 tables of the two coefficient contexts and of the edge-count model */
+__device__ void mp_tables(const DevFrame &F, Sh &sh, int level)
+{
+    const int tid = threadIdx.x;
+    if (tid < F.dcs)
+        sh.lgdc[tid] = log2((double) (sh.coeff[tid] / (float) sh.coeff_tot[0]));
+    else if (tid >= 64 && tid < 64 + F.sy) {
+        int sym = tid - 64, ctx = level - F.lc_min;
+        sh.lglv[sym] = log2((double) (sh.coeff[F.dcs + ctx * F.sy + sym] / (float) sh.coeff_tot[ctx + 1]));
+    } else if (tid >= 128 && tid < 128 + MAXED + 1)
+        sh.Ltab[tid - 128] = (float) -log2((double) (sh.pool.count[tid - 128] / (float) sh.pool.total));
+    else if (tid == 192) {
+        /* nested domain-0 model, gray: y_state < 0 (domain-pool.c:367-402,773-782) */
+        float q0 = 0, q1 = 0;
+        if (sh.pool.d0_n) {
+            float m0 = sh.m0tab[qac_shift(sh.pool.d0_index)];
+            float m1 = (float) qac_shift(sh.pool.d0_index);
+            q0 += m0;
+            q1 += m0; q1 -= m0; q1 += m1;
+        }
+        sh.Q0 = q0; sh.Q1 = q1;
+    }
+}
+
+/* serial part of a step start: sorted list of kept vectors, the two stage-1 weight prices */
+__device__ void mp_step_prepare(const DevFrame &F, Sh &sh)
+{
+    MPState &mp = sh.mp;
+    float wb = 0;
+    int np = 0;
+    for (int k = 0; k < mp.n; k++)
+        if (mp.weight[k] != 0) {
+            if (mp.into[k]) wb = (float) ((double) wb - sh.lglv[rtob_dev(mp.weight[k], F.rpf_mant, F.rpf_range)]);
+            else            wb = (float) ((double) wb - sh.lgdc[rtob_dev(mp.weight[k], F.dc_mant, F.dc_range)]);
+            int j = np++;
+            while (j > 0 && mp.psorted[j - 1] > mp.indices[k]) { mp.psorted[j] = mp.psorted[j - 1]; j--; }
+            mp.psorted[j] = mp.indices[k];
+        }
+    mp.np = np;
+    mp.wb_nd = (float) ((double) wb - sh.lglv[rtob_dev(0.5f, F.rpf_mant, F.rpf_range)]);
+    mp.wb_dc = (float) ((double) wb - sh.lgdc[rtob_dev(0.5f, F.dc_mant, F.dc_range)]);
+    mp.min_costs = mp.costs;            /* full_search is off in this build */
+    mp.b_index = -1;
+}
+
+/* rle_update + aac_update on acceptance (domain-pool.c:795-830, coeff.c:242-267) */
+__device__ void models_update(const DevFrame &F, Sh &sh, const short *indices, const short *into,
+                              const float *weight, int level)
+{
+    Pool &m = sh.pool;
+    int state_0 = 0, edge = 0;
+    for (; indices[edge] != NOEDGE; edge++)
+        if (into[edge] == 0) state_0 = 1;
+    m.count[edge]++;
+    m.total++;
+    if (m.d0_n) {
+        m.d0_index++;
+        if (state_0) { m.d0_index--; m.d0_index >>= 1; }
+        if (m.d0_index > 1020) m.d0_index = 1020;
+    }
+    m.y_index++;                                   /* gray: the y state is never used */
+    if (m.y_index > 1020) m.y_index = 1020;
+    int ctx = level - F.lc_min;
+    for (int e = 0; into[e] != NOEDGE; e++)
+        if (into[e]) {
+            sh.coeff[F.dcs + ctx * F.sy + rtob_dev(weight[e], F.rpf_mant, F.rpf_range)]++;
+            sh.coeff_tot[ctx + 1]++;
+        } else {
+            sh.coeff[rtob_dev(weight[e], F.dc_mant, F.dc_range)]++;
+            sh.coeff_tot[0]++;
+        }
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+/* approximate_range (codec/approx.c:74-271) at optimisation level 0 */
+__device__ void op_approx(DevFrame &F, Sh &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = F.P;
+    SFrame &fr = sh.st[sh.sp];
+    MPState &mp = sh.mp;
+    const int level = fr.lrange.level;
+    const float size = (float) (1u << level);
+    const int q = level - F.images_level;          /* Gram table index of this level */
+    const int D = sh.pool.n;
+
+    mp_tables(F, sh, level);
+    __syncthreads();
+    if (tid == 0) {
+        mp.n = 0; mp.best_n = 0;
+        mp.D = D; mp.N = D;
+        mp.level = level; mp.image = fr.lrange.image; mp.address = fr.lrange.address;
+        mp.norm = F.norms[mp.image];
+        mp.ab = fr.lrange.tree_bits;
+        mp.price = fr.price;
+        mp.err = mp.norm;
+        mp.weights_bits = 0;
+        mp.matrix_bits = pool_bits_sorted(nullptr, 0, sh);
+        mp.costs = (mp.matrix_bits + mp.weights_bits + mp.ab) * mp.price + mp.err;
+        mp.index = -1;
+        mp_step_prepare(F, sh);
+    }
+    __syncthreads();
+
+    const int nblk = (D + 63) >> 6;
+    for (;;) {
+        const int n = mp.n;
+        /* ---------------- phase A: Gram-Schmidt update + stage-1 estimate ---------------- */
+        {
+            const float *Grow = n ? GRAM(F, q) + (size_t) mp.row_state * P : nullptr;
+            const int nv = n - 1;
+            float novk[MAXED], selk[MAXED], nov_nv = 1, ipio_nv = 0;
+            for (int k = 0; k < nv; k++) { novk[k] = mp.norm_ov[k]; selk[k] = mp.sel_ipdo[nv][k]; }
+            if (n) { nov_nv = mp.norm_ov[nv]; ipio_nv = mp.ipio[nv]; }
+            for (int base = 0; base < nblk * 64; base += B) {
+                int d = base + tid;
+                float e = BIGF;
+                if (d < D) {
+                    int s = F.pool_states[d];
+                    bool u;
+                    float num = 0, den = 1;
+                    if (n == 0) {
+                        den = F.diag[(size_t) q * P + s];
+                        u = den / size < MIN_NORM;
+                        if (!u) {
+                            num = F.ipis[(size_t) mp.image * P + s];
+                            u = fabsf(num) < MIN_NORM;
+                        }
+                        F.num[d] = num; F.den[d] = den; F.used[d] = u;
+                    } else {
+                        u = F.used[d];
+                        if (!u) {
+                            num = F.num[d]; den = F.den[d];
+                            float t = Grow[s];
+                            for (int k = 0; k < nv; k++)
+                                t -= F.ipdo[(size_t) k * P + d] / novk[k] * selk[k];
+                            F.ipdo[(size_t) nv * P + d] = t;
+                            den -= t * t / nov_nv;
+                            num -= ipio_nv / nov_nv * t;
+                            if (den / size < MIN_NORM) { u = true; F.used[d] = 1; }
+                            F.num[d] = num; F.den[d] = den;
+                        }
+                    }
+                    if (!u) e = stage1(sh, d, s, num, den);
+                    F.est[d] = e;
+                }
+                float bm = wave_min(e);
+                if (lane == 0 && (base >> 6) + wave < 512) sh.blockmin[(base >> 6) + wave] = bm;
+            }
+        }
+        __syncthreads();
+        /* ---------------- phase B: ordered replay (wave 0) ---------------- */
+        if (wave == 0) {
+            float m = mp.min_costs;
+            unsigned evals = 0;
+            for (int bb = 0; bb < nblk; bb += 64) {
+                float bm = (bb + lane < nblk) ? sh.blockmin[bb + lane] : BIGF;
+                int lastb = -1;
+                for (;;) {
+                    unsigned long long mask = __ballot(bm < m && lane > lastb);
+                    if (!mask) break;
+                    int jb = __ffsll((long long) mask) - 1;
+                    lastb = jb;
+                    int d = ((bb + jb) << 6) + lane;
+                    float e = (d < D) ? F.est[d] : BIGF;
+                    bool pass = e < m;
+                    Eval ev;
+                    ev.costs = BIGF;
+                    if (pass) full_eval(F, sh, d, F.pool_states[d], F.num[d], F.den[d], ev);
+                    evals += (unsigned) __popcll(__ballot(pass));
+                    int last = -1;
+                    for (;;) {
+                        unsigned long long ok = __ballot(pass && lane > last && e < m && ev.costs < m);
+                        if (!ok) break;
+                        int j = __ffsll((long long) ok) - 1;
+                        last = j;
+                        m = __shfl(ev.costs, j);
+                        if (lane == j) {
+                            mp.b_index = d; mp.b_cost = ev.costs; mp.b_mbits = ev.m_bits;
+                            mp.b_wbits = ev.w_bits; mp.b_err = ev.m_err;
+                            for (int k = 0; k <= n; k++) mp.b_f[k] = ev.f[k];
+                        }
+                    }
+                }
+            }
+            if (lane == 0) F.n_fulleval += evals;
+        }
+        __syncthreads();
+        /* ---------------- commit (lane 0) ---------------- */
+        if (tid == 0) {
+            int index = mp.b_index;
+            if (index >= 0) {
+                if (mp.b_cost < mp.costs) {
+                    mp.costs = mp.b_cost; mp.err = mp.b_err;
+                    mp.matrix_bits = mp.b_mbits; mp.weights_bits = mp.b_wbits;
+                    for (int k = 0; k <= n; k++) mp.weight[k] = mp.b_f[k];
+                    mp.best_n = n + 1;
+                }
+                mp.indices[n] = (short) index;
+                mp.into[n] = F.pool_states[index];
+                F.used[index] = 1;
+                mp.norm_ov[n] = F.den[index];
+                mp.ipio[n] = F.num[index];
+                for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + index];
+                mp.row_state = mp.into[n];
+                mp.n = n + 1;
+                if (mp.n < F.max_elements) mp_step_prepare(F, sh);
+            }
+            mp.index = index;
+        }
+        __syncthreads();
+        if (!(mp.n < F.max_elements && mp.index >= 0)) break;
+    }
+
+    if (tid == 0) {
+        Range &lr = fr.lrange;
+        mp.indices[mp.best_n] = NOEDGE;
+        float costs = (mp.matrix_bits + mp.weights_bits + mp.ab) * mp.price + mp.err;
+        if (costs < fr.max_costs) {
+            int ni = 0;
+            for (int oi = 0; mp.indices[oi] != NOEDGE; oi++)
+                if (mp.weight[oi] != 0) {
+                    mp.indices[ni] = mp.indices[oi]; mp.into[ni] = mp.into[oi];
+                    mp.weight[ni] = mp.weight[oi];
+                    ni++;
+                }
+            mp.indices[ni] = NOEDGE; mp.into[ni] = NOEDGE;
+            models_update(F, sh, mp.indices, mp.into, mp.weight, level);
+            int e = 0;
+            for (; mp.indices[e] != NOEDGE; e++) { lr.into[e] = mp.into[e]; lr.weight[e] = mp.weight[e]; }
+            lr.into[e] = NOEDGE;
+            lr.matrix_bits = mp.matrix_bits; lr.weights_bits = mp.weights_bits; lr.err = mp.err;
+        } else {
+            lr.into[0] = NOEDGE;
+            costs = MAXCOSTS;
+        }
+        fr.lincomb = costs;
+        if (F.trace && F.trace_n < F.trace_cap) {
+            FcTrace &t = F.trace[F.trace_n];
+            t.seq = F.trace_n; t.level = level; t.image = mp.image; t.D = D; t.states = sh.states;
+            t.cost = costs; t.err = mp.err; t.mbits = mp.matrix_bits; t.wbits = mp.weights_bits;
+            int e = 0;
+            for (; e < 6; e++) { t.into[e] = -1; if (e < 5) t.w[e] = 0; }
+            for (e = 0; costs < MAXCOSTS && lr.into[e] != NOEDGE; e++) { t.into[e] = lr.into[e]; t.w[e] = lr.weight[e]; }
+            t.nedges = e;
+            F.trace_n++;
+        }
+        F.bytes_mp += 4ull * D * (2 + mp.n) + 4ull * (1u << level);
+        F.n_mp++; F.n_steps += mp.n;
+    }
+}
+
+/* ------------------------------------------------------------------ serial state machine */
+
+__device__ float tree_bits_dev(const Sh &sh, int ML, int child, int level, int which)
+{
+    const unsigned *counts = sh.tm + which * 2 * ML;
+    float prob = counts[level] / (float) counts[ML + level];
+    return child ? (float) -log2((double) prob) : (float) -log2((double) (1 - prob));
+}
+
+__device__ void tree_update_dev(Sh &sh, int ML, int child, int level, int which)
+{
+    unsigned *counts = sh.tm + which * 2 * ML;
+    if (child) counts[level]++;
+    counts[ML + level]++;
+}
+
+__device__ void snap_save(const DevFrame &F, Sh &sh, int depth, int which)
+{
+    short *dst = sh.snap_coeff[depth][which];
+    for (int i = 0; i < F.coeff_size; i++) dst[i] = sh.coeff[i];
+    for (int i = 0; i < F.coeff_nt; i++) dst[FC_MAXCOEFF + i] = sh.coeff_tot[i];
+}
+
+__device__ void snap_load(const DevFrame &F, Sh &sh, int depth, int which)
+{
+    const short *src = sh.snap_coeff[depth][which];
+    for (int i = 0; i < F.coeff_size; i++) sh.coeff[i] = src[i];
+    for (int i = 0; i < F.coeff_nt; i++) sh.coeff_tot[i] = src[FC_MAXCOEFF + i];
+}
+
+/* wfalib.c:152-180 */
+__device__ float final_distribution_dev(const DevFrame &F, int s)
+{
+    float f = 0;
+    int dom;
+    for (int l = 0; l < 2; l++) {
+        if ((dom = TREE(F, s, l)) != RANGE_) f += F.final_d[dom];
+        for (int e = 0; (dom = INTO(F, s, l, e)) != NOEDGE; e++)
+            f += WEIGHT(F, s, l, e) * F.final_d[dom];
+    }
+    return f / 2;
+}
+
+/* init_new_state (codec/subdivide.c:549-610): store the new state's rows; edge lists are
+ * kept sorted by target like append_edge (codec/wfalib.c:233-275) */
+__device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
+{
+    const int s = sh.states;
+    if (!aux && sh.pool.n < sh.pool.max_domains) F.pool_states[sh.pool.n++] = (short) s;
+    fr.rrange.into[0] = NOEDGE;
+    fr.rrange.tree = s;
+    for (int l = 0; l < 2; l++) {
+        const Range &ch = fr.child[l];
+        TREE(F, s, l) = (short) ch.tree;
+        F.x[l * F.P + s] = (uint16_t) ch.x;
+        F.y[l * F.P + s] = (uint16_t) ch.y;
+        short si[MAXED + 1]; float sw[MAXED + 1];
+        int ne = 0;
+        for (int e = 0; ch.into[e] != NOEDGE; e++) {
+            int pos = 0;
+            while (pos < ne && si[pos] < ch.into[e]) pos++;
+            for (int j = ne; j > pos; j--) { si[j] = si[j - 1]; sw[j] = sw[j - 1]; }
+            si[pos] = ch.into[e]; sw[pos] = ch.weight[e];
+            ne++;
+        }
+        for (int e = 0; e < ne; e++) { INTO(F, s, l, e) = si[e]; WEIGHT(F, s, l, e) = sw[e]; }
+        INTO(F, s, l, ne) = NOEDGE;
+    }
+    F.final_d[s] = final_distribution_dev(F, s);
+    F.level_of_state[s] = (uint8_t) fr.rrange.level;
+    F.domain_type[s] = aux ? 0 : 2;
+}
+
+/* advance the partition search until a data-parallel operation is required */
+__device__ void serial_advance(DevFrame &F, Sh &sh)
+{
+    const int ML = F.ML;
+    for (;;) {
+        if (sh.sp < 0) { sh.op = OP_DONE; return; }
+        SFrame &fr = sh.st[sh.sp];
+        switch (fr.phase) {
+        case PH_ENTER: {
+            Range &rg = fr.rg;
+            rg.into[0] = NOEDGE;
+            rg.tree = RANGE_;
+            fr.ret = MAXCOSTS;
+            if (sh.failed || rg.level < 3) { fr.ret = MAXCOSTS; goto pop; }
+            if (rg.x >= F.width || rg.y >= F.height) { fr.ret = 0; goto pop; }
+            fr.price = F.price;
+            fr.phase = PH_AFTER_INIT;
+            if (rg.level == F.lc_max) {
+                rg.address = rg.image = 0;
+                sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
+                return;
+            }
+            break;
+        }
+        case PH_AFTER_INIT: {
+            Range &rg = fr.rg;
+            fr.pool0 = sh.pool;
+            snap_save(F, sh, sh.sp, 0);
+            for (int i = 0; i < 4 * ML; i++) sh.snap_tm[sh.sp][i] = sh.tm[i];
+            fr.states = sh.states;
+            fr.phase = PH_AFTER_LC;
+            if (rg.level <= F.lc_max) {
+                fr.lrange = rg;
+                fr.lrange.tree = RANGE_;
+                fr.lrange.tree_bits = tree_bits_dev(sh, ML, 0, rg.level, 0);
+                fr.lrange.matrix_bits = 0;
+                fr.lrange.weights_bits = 0;
+                sh.op = OP_APPROX;
+                return;
+            }
+            fr.lincomb = MAXCOSTS;
+            break;
+        }
+        case PH_AFTER_LC: {
+            Range &rg = fr.rg;
+            fr.pool_lc = sh.pool;
+            snap_save(F, sh, sh.sp, 1);
+            sh.pool = fr.pool0;
+            snap_load(F, sh, sh.sp, 0);
+            if (rg.level > F.lc_min) {
+                Range z;
+                z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
+                for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
+                z.err = z.tree_bits = z.matrix_bits = z.weights_bits = 0;
+                fr.child[0] = z; fr.child[1] = z;
+                fr.rrange = rg;
+                fr.rrange.tree_bits = tree_bits_dev(sh, ML, 1, rg.level, 0);
+                fr.rrange.matrix_bits = 0;
+                fr.rrange.weights_bits = 0;
+                fr.rrange.err = 0;
+                fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits) * fr.price;
+                fr.label = 0;
+                fr.phase = PH_CHILD;
+            } else {
+                fr.subdiv = MAXCOSTS;
+                fr.phase = PH_DECIDE;
+            }
+            break;
+        }
+        case PH_CHILD: {
+            const Range &rr = fr.rrange;
+            const int label = fr.label;
+            Range &ch = fr.child[label];
+            ch.image = rr.image * 2 + label + 1;
+            ch.address = rr.address * 2 + label;
+            ch.level = rr.level - 1;
+            ch.x = (rr.level & 1) ? rr.x : rr.x + label * (int) width_of_level(rr.level - 1);
+            ch.y = (rr.level & 1) ? rr.y + label * (int) height_of_level(rr.level - 1) : rr.y;
+            fr.phase = PH_CHILD2;
+            if (label && rr.level <= F.lc_max && sh.states > fr.states) {
+                sh.op = OP_IPIS_INCR; sh.a0 = ch.image; sh.a1 = ch.address; sh.a2 = ch.level;
+                sh.a3 = fr.states;
+                return;
+            }
+            break;
+        }
+        case PH_CHILD2: {
+            float lim = fr.lincomb > fr.max_costs ? fr.max_costs : fr.lincomb;
+            float remaining = lim - fr.subdiv;
+            fr.phase = PH_CHILD_RET;
+            fr.ret = 0;
+            if (remaining > 0) {
+                if (sh.sp + 1 >= FC_MAXDEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
+                SFrame &cf = sh.st[sh.sp + 1];
+                cf.rg = fr.child[fr.label];
+                cf.max_costs = remaining;
+                cf.phase = PH_ENTER;
+                sh.sp++;
+                break;                              /* child result arrives in fr.ret */
+            }
+            fr.ret = -1;                            /* marker: no recursion happened */
+            break;
+        }
+        case PH_CHILD_RET: {
+            const int label = fr.label;
+            float lim = fr.lincomb > fr.max_costs ? fr.max_costs : fr.lincomb;
+            if (fr.ret >= 0) fr.subdiv += fr.ret;
+            if (fr.subdiv >= lim) {
+                fr.subdiv = MAXCOSTS;
+                fr.phase = PH_DECIDE;
+                break;
+            }
+            const Range &ch = fr.child[label];
+            fr.rrange.err          += ch.err;
+            fr.rrange.tree_bits    += ch.tree_bits;
+            fr.rrange.matrix_bits  += ch.matrix_bits;
+            fr.rrange.weights_bits += ch.weights_bits;
+            tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
+            tree_update_dev(sh, ML, 1, ch.level, 1);
+            fr.label = label + 1;
+            fr.phase = fr.label < 2 ? PH_CHILD : PH_DECIDE;
+            break;
+        }
+        case PH_DECIDE: {
+            Range &rg = fr.rg;
+            if (fr.lincomb >= MAXCOSTS && fr.subdiv >= MAXCOSTS) {
+                sh.pool = fr.pool0;
+                snap_load(F, sh, sh.sp, 0);
+                for (int i = 0; i < 4 * ML; i++) sh.tm[i] = sh.snap_tm[sh.sp][i];
+                sh.states = fr.states;
+                fr.ret = MAXCOSTS;
+                goto pop;
+            } else if (fr.lincomb < fr.subdiv) {
+                sh.pool = fr.pool_lc;
+                snap_load(F, sh, sh.sp, 1);
+                for (int i = 0; i < 4 * ML; i++) sh.tm[i] = sh.snap_tm[sh.sp][i];
+                rg = fr.lrange;
+                sh.states = fr.states;
+                fr.ret = fr.lincomb;
+                goto pop;
+            } else {
+                int aux = rg.x + (int) width_of_level(rg.level) > F.width
+                          || rg.y + (int) height_of_level(rg.level) > F.height;
+                if (sh.states >= F.P) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+                store_new_state(F, sh, fr, aux);
+                fr.phase = PH_AFTER_APPEND;
+                if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return; }
+                break;
+            }
+        }
+        case PH_AFTER_APPEND: {
+            sh.states++;
+            if (sh.states >= F.limit_states) sh.failed = FC_ERR_STATES;
+            fr.rg = fr.rrange;
+            fr.ret = fr.subdiv;
+            goto pop;
+        }
+        }
+        continue;
+    pop:
+        if (sh.sp > 0) {
+            SFrame &pf = sh.st[sh.sp - 1];
+            pf.child[pf.label] = fr.rg;
+            pf.ret = fr.ret;
+        }
+        sh.sp--;
+    }
+}
+
+/* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
+__device__ void basis_init(DevFrame &F, Sh &sh)
+{
+    const int nb = F.basis_states, il = F.images_level;
+    for (int s = 0; s < nb; s++) {
+        F.img[(size_t) s * F.NI] = F.final_d[s];
+        if (il == 0) F.imgT[s] = F.final_d[s];
+    }
+    for (int l = 1; l <= il; l++)
+        for (int s = 0; s < nb; s++)
+            for (int i = 0; i < (1 << l); i++) {
+                float v = image_elem(F, s, l, i);
+                F.img[(size_t) s * F.NI + (1 << l) - 1 + i] = v;
+                if (l == il) F.imgT[(size_t) i * F.P + s] = v;
+            }
+    for (int q = 0; q < F.NL; q++)
+        for (int s1 = 0; s1 < nb; s1++)
+            for (int s2 = 0; s2 <= s1; s2++) {
+                if (!F.domain_type[s2]) continue;
+                gram_store(F, q, s1, s2, q == 0 ? gram_dot(F, s1, s2) : gram_entry(F, q, s1, s2));
+            }
+    sh.states = nb;
+}
+
+__global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
+{
+    __shared__ Sh sh;
+    DevFrame &F = frames[blockIdx.x];
+    const int tid = threadIdx.x;
+
+    if (tid < 10 && tid >= 1)
+        sh.m0tab[tid] = (float) -log2((double) (1 - 1 / (float) (1 << tid)));
+    if (tid == 0) {
+        const int ML = F.ML;
+        static const unsigned c0[22] = {20,17,15,10,5,4,3,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1};
+        static const unsigned c1[22] = {1,1,1,1,1,1,1,1,1,2,3,5,10,15,20,25,30,35,60,60,60,60};
+        sh.failed = 0;
+        for (int w = 0; w < 2; w++)
+            for (int l = 0; l < ML; l++) {
+                int k = l < 22 ? l : 21;
+                sh.tm[w * 2 * ML + l] = c1[k];
+                sh.tm[w * 2 * ML + ML + l] = c0[k] + c1[k];
+            }
+        for (int i = 4 * ML; i < 4 * 26 + 8; i++) sh.tm[i] = 0;
+        /* rle pool over the usable basis states (domain-pool.c:632-676) */
+        Pool &m = sh.pool;
+        m.total = 0;
+        for (int i = 0; i <= MAXED; i++) { m.count[i] = 1; m.total++; }
+        m.n = 0; m.max_domains = (unsigned short) F.pool_max; m.y_index = 0;
+        m.d0_index = 0; m.d0_yindex = 0; m.d0_n = 0;
+        for (int s = 0; s < F.basis_states; s++)
+            if ((F.domain_type[s] & 2) && m.n < m.max_domains) {
+                F.pool_states[m.n++] = (short) s;
+                if (s == 0) m.d0_n = 1;
+            }
+        /* aac model, all-ones (coeff.c:297-310) */
+        for (int i = 0; i < F.coeff_size; i++) sh.coeff[i] = 1;
+        sh.coeff_tot[0] = (short) F.dcs;
+        for (int i = 1; i < F.coeff_nt; i++) sh.coeff_tot[i] = (short) F.sy;
+        basis_init(F, sh);
+        /* root range (codec/coder.c:738-745) */
+        SFrame &r = sh.st[0];
+        r.rg.x = r.rg.y = r.rg.image = r.rg.address = 0;
+        r.rg.level = F.level; r.rg.tree = RANGE_;
+        for (int i = 0; i <= MAXED; i++) { r.rg.weight[i] = 0; r.rg.into[i] = 0; }
+        r.rg.err = r.rg.tree_bits = r.rg.matrix_bits = r.rg.weights_bits = 0;
+        r.max_costs = MAXCOSTS;
+        r.phase = PH_ENTER;
+        sh.sp = 0;
+        serial_advance(F, sh);
+    }
+    for (;;) {
+        __syncthreads();
+        const int op = sh.op;
+        if (op == OP_DONE) break;
+        switch (op) {
+        case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1); break;
+        case OP_APPROX:     op_approx(F, sh); break;
+        case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
+        case OP_APPEND:     op_append(F, sh, sh.a0); break;
+        }
+        __syncthreads();
+        if (tid == 0) serial_advance(F, sh);
+    }
+    if (tid == 0) {
+        const Range &rg = sh.st[0].rg;
+        F.states = sh.states;
+        F.root_state = rg.tree;
+        F.costs = sh.st[0].ret;
+        F.err = rg.err; F.tree_bits = rg.tree_bits;
+        F.matrix_bits = rg.matrix_bits; F.weights_bits = rg.weights_bits;
+        F.status = sh.failed ? sh.failed : (rg.tree == RANGE_ ? FC_ERR_NOROOT : FC_OK);
+    }
+}
+
+extern "C" void fc_launch(DevFrame *d_frames, unsigned n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fiasco_frame_kernel, dim3(n), dim3(B), 0, stream, d_frames);
+}

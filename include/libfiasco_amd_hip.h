@@ -1,0 +1,38 @@
+/*
+ *  libfiasco_amd_hip.h -- measurement hooks of the HIP hot path (C ABI, plain types).
+ *
+ *  The data-path boundary itself is fiasco_coder() / fiasco_amd_encode_batch() in
+ *  libfiasco_amd.h; what is declared here only reports what the device coder did, so that
+ *  bench.py can compute the roofline figures from the coder's OWN per-call counters
+ *   and from HIP-event time measured on the stream the kernel ran on.
+ */
+#ifndef LIBFIASCO_AMD_HIP_H
+#define LIBFIASCO_AMD_HIP_H 1
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fiasco_amd_stats {
+    double             kernel_ms;   /* sum of HIP-event durations of fiasco_frame_kernel     */
+    unsigned long long launches;    /* kernel launches                                       */
+    unsigned long long frames;      /* frames encoded successfully                           */
+    /* algorithmic bytes, summed per call from the coder's counters:
+     *   bytes_mp   = sum over matching-pursuit calls of 4*D*(2+S) + 4*2^L
+     *   bytes_img  = sum over init_range blocks of N*(128+4*NS) + 4*2^lc_max
+     *   bytes_gram = sum over appended states of 4*(NL-1)*(s+1)*(1+E) + 8*NL*(s+1)        */
+    unsigned long long bytes_mp, bytes_img, bytes_gram;
+    unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
+} fiasco_amd_stats;
+
+void fiasco_amd_get_stats(fiasco_amd_stats *out);
+void fiasco_amd_reset_stats(void);
+
+/* name of the hot-path backend linked into this library: "hip-gfx950" for the product,
+ * "oracle-cpu" for the test-only oracle library (reference seam: codec/approx.h:24-27,
+ * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */
+const char *fa_core_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

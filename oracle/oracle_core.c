@@ -79,6 +79,8 @@ typedef struct oc {
     float     norm_ov[MAXED + 1], ipio[MAXED + 1];
     char      err[160];
     int       failed;
+    FILE     *trace;                    /* FIASCO_ORACLE_TRACE: one record per approximate_range */
+    int       trace_n;
 } oc;
 
 static float *img_of(oc *c, unsigned s) { return c->images + (size_t) s * c->nimg; }
@@ -789,6 +791,19 @@ static float approximate_range(oc *c, float max_costs, float price, unsigned max
         rg->into[0] = FA_NO_EDGE;
         mp.costs = FA_MAXCOSTS;
     }
+    if (c->trace) {
+        struct { int seq, level, image, D, states, nedges; float cost, err, mbits, wbits;
+                 short into[6]; float w[5]; } t;
+        int e;
+        memset(&t, 0, sizeof t);
+        t.seq = c->trace_n++; t.level = (int) rg->level; t.image = (int) rg->image;
+        t.D = (int) c->pool.n; t.states = (int) c->w->states;
+        t.cost = mp.costs; t.err = mp.err; t.mbits = mp.matrix_bits; t.wbits = mp.weights_bits;
+        for (e = 0; e < 6; e++) t.into[e] = -1;
+        for (e = 0; mp.costs < FA_MAXCOSTS && rg->into[e] != FA_NO_EDGE; e++) { t.into[e] = rg->into[e]; t.w[e] = rg->weight[e]; }
+        t.nedges = e;
+        fwrite(&t, sizeof t, 1, c->trace);
+    }
     return mp.costs;
 }
 
@@ -1017,6 +1032,7 @@ static int encode_one(fa_job *job)
     c.used = (uint8_t *) calloc(cap + 2, 1);
     c.dlist = (int16_t *) calloc(cap + 4, sizeof(int16_t));
     init_matrix_tables(&c);
+    if (getenv("FIASCO_ORACLE_TRACE")) c.trace = fopen(getenv("FIASCO_ORACLE_TRACE"), "wb");
 
     append_basis_states(&c);
     tree_init(c.tm, c.tm + c.ML, c.ML);
@@ -1071,6 +1087,7 @@ static int encode_one(fa_job *job)
     job->status = !c.failed;
     if (c.failed) snprintf(job->errmsg, sizeof job->errmsg, "%s", c.err);
 
+    if (c.trace) fclose(c.trace);
     for (s = 0; s < cap; s++) free(c.gram[s]);
     free(c.images); free(c.ipis); free(c.gram); free(c.pixels); free(c.tm); free(c.pool_states);
     free(c.rem_num); free(c.rem_den); free(c.ipdo); free(c.used); free(c.dlist);

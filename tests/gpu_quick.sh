@@ -1,0 +1,26 @@
+#!/bin/bash
+# developer helper: device-vs-oracle stream + per-call trace comparison
+# usage: tests/gpu_quick.sh [name ...]   (names: g96 g256 n512 g720 g1080)
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out/q
+names="${*:-n512 g720}"
+python3 - $names <<'PY'
+import sys; sys.path.insert(0,'tests')
+from synth import *
+gen = {'g96': lambda: synth(96,64,5), 'g256': lambda: synth(256,256,1234), 'n512': noise,
+       'g720': lambda: synth(1280,720,1234), 'g1080': lambda: synth(1920,1080,1234)}
+for n in sys.argv[1:]:
+    write_pgm('gpurun_out/q/%s.pgm' % n, gen[n]())
+PY
+for f in $names; do
+  s0=$(date +%s%N)
+  FIASCO_ORACLE_TRACE=gpurun_out/q/$f.or.trace oracle/cfiasco_oracle --progress-meter 0 -o gpurun_out/q/$f.or.fco gpurun_out/q/$f.pgm
+  s1=$(date +%s%N)
+  FIASCO_AMD_TRACE=gpurun_out/q/$f.gpu.trace timeout 300 fiasco_amd/bin/cfiasco --progress-meter 0 -o gpurun_out/q/$f.gpu.fco gpurun_out/q/$f.pgm
+  s2=$(date +%s%N)
+  echo "$f: oracle $(( (s1-s0)/1000000 )) ms, device $(( (s2-s1)/1000000 )) ms (process start + hip init included)"
+  echo "$f: oracle $(stat -c %s gpurun_out/q/$f.or.fco) $(md5sum < gpurun_out/q/$f.or.fco | cut -c1-12)  device $(stat -c %s gpurun_out/q/$f.gpu.fco) $(md5sum < gpurun_out/q/$f.gpu.fco | cut -c1-12)"
+  python3 tests/trace_diff.py gpurun_out/q/$f.or.trace gpurun_out/q/$f.gpu.trace
+done
+rm -f gpurun_out/q/*.trace gpurun_out/q/*.pgm

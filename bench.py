@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- grayscale frames/s encoded by the HIP hot path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic frames per GPU: F
+independent 1920x1080 grayscale frames (BASELINE config 2: CLI defaults, -q 20, 8x8 px
+minimum range blocks, default dictionary), all in flight at once -- one persistent
+workgroup per frame -- through the C-ABI entry fiasco_amd_encode_batch().  Inputs are
+already decoded PNM buffers in host memory; the pixel planes are uploaded inside the call,
+so `value` (whole job frames/s over the barrier-bracketed wall time) INCLUDES the PCIe
+upload and the host-side .fco entropy writer, i.e. it is a lower bound of the
+HBM-resident rate.  The kernel-only rate is reported next to it.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  Frames are
+independent units, so every rank encodes its own F frames (weak scaling)
+with no data-path collective; the finished byte strings are gathered over RCCL after the
+timed region's last step (fiasco_amd/sharding.py) and rank 0 checks them.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+REF_MD5_SEED1234 = "c7a9f8a7029644d5fed0dc0583e8b478"   # reference stream of the 1080p survey image
+
+
+def cpu_baseline(frame_pnm):
+    """Time the CPU coder on the host cores of this box on a bounded sample (1 frame of the
+    same workload, 1 thread: the reference algorithm is single threaded).  Uses the real
+    reference binary when the prebuilt oracle/_ref travels with the repo, else the port."""
+    tmp = "/tmp/fiasco_bench_cpu"
+    os.makedirs(tmp, exist_ok=True)
+    src = os.path.join(tmp, "frame.pgm")
+    open(src, "wb").write(frame_pnm)
+    out = os.path.join(tmp, "frame.fco")
+    ref = os.path.join(ROOT, "oracle", "_ref", "cfiasco_ref")
+    port = os.path.join(ROOT, "oracle", "cfiasco_oracle")
+    env = dict(os.environ, FIASCO_DATA=os.path.join(ROOT, "fiasco_amd", "data"))
+    for kind, exe in (("reference", ref), ("port", port)):
+        if not os.path.exists(exe):
+            continue
+        try:
+            t0 = time.time()
+            r = subprocess.run([exe, "--progress-meter", "0", "-o", out, src], env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            dt = time.time() - t0
+        except Exception:
+            continue
+        if r.returncode == 0 and os.path.exists(out):
+            md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
+            return {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": kind,
+                    "sample": "1 frame 1920x1080 gray, -q 20 -z 0, %.1f s, stream md5 %s" % (dt, md5[:12])}
+    return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "cpu coder unavailable"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=256)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import synth
+    import fiasco_amd
+    from fiasco_amd.sharding import gather_streams
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    lib = fiasco_amd.library()
+    lib.set_verbosity(0)
+    lib.set_device(local)
+    opt = lib.cli_options()
+
+    F = a.frames_per_gpu
+    # frame 0 of rank 0 is the survey image (seed 1234) whose reference stream md5 is known
+    seeds = [1234 + 7919 * rank] + [1000 + 100 * rank + i for i in range(1, a.distinct)]
+    uniq = [synth.pgm_bytes(synth.synth(a.width, a.height, s)) for s in seeds]
+    frames = [uniq[i % len(uniq)] for i in range(F)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(a.warmup):
+        out = lib.encode_batch(frames, 20.0, opt)
+    barrier()
+    lib.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = lib.encode_batch(frames, 20.0, opt)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = lib.get_stats()
+    assert out is not None and all(o is not None for o in out), lib.error_message()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(st.kernel_ms), float(st.bytes_mp + st.bytes_img + st.bytes_gram),
+                        float(st.launches), float(st.frames)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        # trivial gather of the per-rank streams over RCCL (outside the timed region)
+        local_streams = {rank * len(uniq) + i: out[i] for i in range(len(uniq))}
+        alls = gather_streams(local_streams, world * len(uniq), device=dev)
+        assert all(s and s[:7] == b"FIASCO\n" for s in alls)
+    dt = float(t.item())
+    kernel_ms, alg_bytes, launches, nframes = [float(x) for x in agg.tolist()]
+
+    if rank == 0:
+        if a.width == 1920 and a.height == 1080:
+            assert hashlib.md5(out[0]).hexdigest() == REF_MD5_SEED1234, "parity lost: stream differs from the reference"
+        total_frames = world * F * a.steps
+        value = total_frames / dt
+        per_launch_bytes = alg_bytes / max(launches, 1)
+        avg_kernel_s = (kernel_ms / 1e3) / max(launches, 1)
+        achieved = per_launch_bytes / avg_kernel_s / 1e9
+        res = {
+            "metric": "grayscale frames/sec encoded",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batch of %d independent %dx%d grayscale PGM frames per GPU, "
+                                   "cfiasco defaults (-q 20, block levels 6..10, 3 elements, small.fco "
+                                   "basis, rle/adaptive models), bit-identical .fco streams"
+                                   % (F, a.width, a.height),
+                       "frames_per_gpu": F, "parallelism": "frames x%d" % world,
+                       "kernel_only_frames_per_s": nframes / (kernel_ms / 1e3) * world if kernel_ms else None,
+                       "parity": "stream md5 of survey frame == reference (%s)" % REF_MD5_SEED1234[:12]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fiasco_frame_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": per_launch_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(uniq[0])
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,236 @@
+"""fiasco_amd -- MI355X-native FIASCO encoder hot path behind the libfiasco C API.
+
+Python here is plumbing only: a ctypes mirror of the C-ABI shared library
+``libfiasco_amd.so`` (host C + hand-written HIP for gfx950).  The names follow the
+reference interface (``fiasco_coder``, ``fiasco_c_options_set_*``; reference fiasco.h:303-398)
+so that tests read like calls into the reference library.
+
+There is no CPU fallback: ``fiasco_coder`` / ``encode_batch`` fail (return 0 / raise) when
+the HIP device coder cannot run.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfiasco_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# enums (values are ABI, include/libfiasco_amd.h)
+FIASCO_NO_VERBOSITY, FIASCO_SOME_VERBOSITY, FIASCO_ULTIMATE_VERBOSITY = 0, 1, 2
+FIASCO_TILING_SPIRAL_ASC, FIASCO_TILING_SPIRAL_DSC = 0, 1
+FIASCO_TILING_VARIANCE_ASC, FIASCO_TILING_VARIANCE_DSC = 2, 3
+FIASCO_RPF_RANGE_0_75, FIASCO_RPF_RANGE_1_00, FIASCO_RPF_RANGE_1_50, FIASCO_RPF_RANGE_2_00 = 0, 1, 2, 3
+FIASCO_PROGRESS_NONE, FIASCO_PROGRESS_BAR, FIASCO_PROGRESS_PERCENT = 0, 1, 2
+
+# every symbol include/libfiasco_amd.h and include/libfiasco_amd_hip.h declare
+EXPORTED_SYMBOLS = [
+    "fiasco_get_error_message", "fiasco_set_verbosity", "fiasco_get_verbosity", "fiasco_coder",
+    "fiasco_c_options_new", "fiasco_c_options_delete", "fiasco_c_options_set_smoothing",
+    "fiasco_c_options_set_frame_pattern", "fiasco_c_options_set_tiling",
+    "fiasco_c_options_set_basisfile", "fiasco_c_options_set_chroma_quality",
+    "fiasco_c_options_set_optimizations", "fiasco_c_options_set_prediction",
+    "fiasco_c_options_set_video_param", "fiasco_c_options_set_quantization",
+    "fiasco_c_options_set_progress_meter", "fiasco_c_options_set_comment",
+    "fiasco_c_options_set_title", "fiasco_calloc", "open_file", "fiasco_amd_set_limits",
+    "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
+    "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
+]
+
+
+class Stats(ctypes.Structure):
+    """struct fiasco_amd_stats (include/libfiasco_amd_hip.h)."""
+    _fields_ = [("kernel_ms", ctypes.c_double), ("launches", ctypes.c_ulonglong),
+                ("frames", ctypes.c_ulonglong), ("bytes_mp", ctypes.c_ulonglong),
+                ("bytes_img", ctypes.c_ulonglong), ("bytes_gram", ctypes.c_ulonglong),
+                ("n_mp", ctypes.c_ulonglong), ("n_steps", ctypes.c_ulonglong),
+                ("n_blocks", ctypes.c_ulonglong), ("n_appends", ctypes.c_ulonglong),
+                ("n_fulleval", ctypes.c_ulonglong), ("t_init", ctypes.c_ulonglong),
+                ("t_approx", ctypes.c_ulonglong), ("t_ipis", ctypes.c_ulonglong),
+                ("t_append", ctypes.c_ulonglong), ("t_serial", ctypes.c_ulonglong),
+                ("t_total", ctypes.c_ulonglong)]
+
+
+def build(verbose=False):
+    """Compile libfiasco_amd.so (gcc for the host C, hipcc --offload-arch=gfx950 for the
+    device coder).  Works without a GPU (cross compilation)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC], stdout=out)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build did not produce %s" % LIB_PATH)
+
+
+class FiascoError(RuntimeError):
+    pass
+
+
+class Library:
+    """ctypes binding of one libfiasco-compatible shared library."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise FiascoError("%s is missing: run fiasco_amd.build() (there is no fallback)" % path)
+        self.path = path
+        L = self.L = ctypes.CDLL(path)
+        c = ctypes
+        L.fiasco_get_error_message.restype = c.c_char_p
+        L.fiasco_set_verbosity.argtypes = [c.c_int]
+        L.fiasco_get_verbosity.restype = c.c_int
+        L.fiasco_c_options_new.restype = c.c_void_p
+        L.fiasco_c_options_delete.argtypes = [c.c_void_p]
+        L.fiasco_coder.argtypes = [c.POINTER(c.c_char_p), c.c_char_p, c.c_float, c.c_void_p]
+        L.fiasco_coder.restype = c.c_int
+        for name, args in [
+            ("set_smoothing", [c.c_int]), ("set_frame_pattern", [c.c_char_p]),
+            ("set_tiling", [c.c_int, c.c_uint]), ("set_basisfile", [c.c_char_p]),
+            ("set_chroma_quality", [c.c_float, c.c_uint]),
+            ("set_optimizations", [c.c_uint] * 5), ("set_prediction", [c.c_int, c.c_uint, c.c_uint]),
+            ("set_video_param", [c.c_uint, c.c_int, c.c_int, c.c_int]),
+            ("set_quantization", [c.c_uint, c.c_int, c.c_uint, c.c_int]),
+            ("set_progress_meter", [c.c_int]), ("set_comment", [c.c_char_p]),
+            ("set_title", [c.c_char_p]),
+        ]:
+            fn = getattr(L, "fiasco_c_options_" + name)
+            fn.argtypes = [c.c_void_p] + args
+            fn.restype = c.c_int
+        L.fiasco_amd_set_limits.argtypes = [c.c_uint, c.c_uint]
+        L.fiasco_amd_set_limits.restype = c.c_int
+        L.fiasco_amd_get_limits.argtypes = [c.POINTER(c.c_uint), c.POINTER(c.c_uint)]
+        L.fiasco_amd_encode_batch.argtypes = [c.c_uint, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t),
+                                              c.c_float, c.c_void_p, c.POINTER(c.c_void_p),
+                                              c.POINTER(c.c_size_t)]
+        L.fiasco_amd_encode_batch.restype = c.c_int
+        L.fiasco_amd_free.argtypes = [c.c_void_p]
+        L.fa_core_name.restype = c.c_char_p
+        if hasattr(L, "fiasco_amd_get_stats"):
+            L.fiasco_amd_get_stats.argtypes = [c.POINTER(Stats)]
+
+    # -- misc ------------------------------------------------------------------
+    def error_message(self):
+        return self.L.fiasco_get_error_message().decode("latin-1")
+
+    def core_name(self):
+        return self.L.fa_core_name().decode()
+
+    def set_verbosity(self, level):
+        self.L.fiasco_set_verbosity(level)
+
+    def set_limits(self, max_states, max_level):
+        if not self.L.fiasco_amd_set_limits(max_states, max_level):
+            raise FiascoError(self.error_message())
+
+    def get_limits(self):
+        a, b = ctypes.c_uint(), ctypes.c_uint()
+        self.L.fiasco_amd_get_limits(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def set_device(self, device):
+        self.L.fiasco_amd_set_device.argtypes = [ctypes.c_int]
+        if not self.L.fiasco_amd_set_device(device):
+            raise FiascoError(self.error_message())
+
+    def get_stats(self):
+        st = Stats()
+        self.L.fiasco_amd_get_stats(ctypes.byref(st))
+        return st
+
+    def reset_stats(self):
+        self.L.fiasco_amd_reset_stats()
+
+    # -- options ---------------------------------------------------------------
+    def c_options_new(self):
+        return COptions(self)
+
+    def cli_options(self, optimize=0, dictionary_size=10000, progress=FIASCO_PROGRESS_NONE, **kw):
+        """Options object configured like reference bin/cwfa.c:252-393 does for the CLI
+        defaults (block levels [6,10] and 3 elements at --optimize 0; [4,12] / 5 above)."""
+        o = self.c_options_new()
+        o.set_frame_pattern(kw.get("pattern", "ippppppppp"))
+        o.set_chroma_quality(kw.get("chroma_qfactor", 2.0), kw.get("chroma_dictionary", 40))
+        o.set_smoothing(kw.get("smooth", 70))
+        o.set_progress_meter(progress)
+        o.set_tiling(FIASCO_TILING_VARIANCE_DSC, kw.get("tiling_exponent", 4))
+        if optimize <= 0:
+            o.set_optimizations(6, 10, 3, dictionary_size, 0)
+        else:
+            o.set_optimizations(4, 12, 5, dictionary_size, optimize - 1)
+        o.set_prediction(0, kw.get("min_level", 6), kw.get("max_level", 10))
+        o.set_quantization(3, FIASCO_RPF_RANGE_1_50, 5, FIASCO_RPF_RANGE_1_00)
+        return o
+
+    # -- coder -----------------------------------------------------------------
+    def fiasco_coder(self, inputnames, outputname, quality=20.0, options=None):
+        """int fiasco_coder(inputname[], outputname, quality, options): 1 ok / 0 failure."""
+        arr = (ctypes.c_char_p * (len(inputnames) + 1))()
+        for i, n in enumerate(inputnames):
+            arr[i] = os.fsencode(n)
+        arr[len(inputnames)] = None
+        return self.L.fiasco_coder(arr, os.fsencode(outputname) if outputname else None,
+                                   ctypes.c_float(quality), options.handle if options else None)
+
+    def encode_batch(self, pnm_list, quality=20.0, options=None):
+        """fiasco_amd_encode_batch: independent stills (raw PNM bytes) -> list of .fco bytes
+        (None for a frame that failed)."""
+        n = len(pnm_list)
+        bufs = (ctypes.c_char_p * n)(*pnm_list)
+        lens = (ctypes.c_size_t * n)(*[len(b) for b in pnm_list])
+        outs = (ctypes.c_void_p * n)()
+        olen = (ctypes.c_size_t * n)()
+        self.L.fiasco_amd_encode_batch(n, bufs, lens, ctypes.c_float(quality),
+                                       options.handle if options else None, outs, olen)
+        res = []
+        for i in range(n):
+            if outs[i]:
+                res.append(ctypes.string_at(outs[i], olen[i]))
+                self.L.fiasco_amd_free(outs[i])
+            else:
+                res.append(None)
+        return res
+
+
+class COptions:
+    """fiasco_c_options_t with the reference's setter names (fiasco.h:132-174)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.handle = lib.L.fiasco_c_options_new()
+        if not self.handle:
+            raise FiascoError(lib.error_message())
+
+    def _call(self, name, *args):
+        conv = [a.encode() if isinstance(a, str) else a for a in args]
+        ok = getattr(self.lib.L, "fiasco_c_options_" + name)(self.handle, *conv)
+        if not ok:
+            raise FiascoError(self.lib.error_message())
+        return ok
+
+    def delete(self):
+        if self.handle:
+            self.lib.L.fiasco_c_options_delete(self.handle)
+            self.handle = None
+
+    def __getattr__(self, name):
+        if name.startswith("set_"):
+            return lambda *a: self._call(name, *a)
+        raise AttributeError(name)
+
+
+_default = None
+
+
+def library():
+    """The product library (HIP hot path).  Raises if it has not been built."""
+    global _default
+    if _default is None:
+        _default = Library(LIB_PATH)
+        if _default.core_name() != "hip-gfx950":
+            raise FiascoError("libfiasco_amd.so is not linked against the HIP device coder")
+    return _default
+
+
+def fiasco_coder(inputnames, outputname, quality=20.0, options=None):
+    return library().fiasco_coder(inputnames, outputname, quality, options)
+
+
+def encode_batch(pnm_list, quality=20.0, options=None):
+    return library().encode_batch(pnm_list, quality, options)

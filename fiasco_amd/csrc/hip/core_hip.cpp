@@ -25,6 +25,16 @@ extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out) { *out = g_stats; }
 extern "C" void fiasco_amd_reset_stats(void) { memset(&g_stats, 0, sizeof g_stats); }
 extern "C" const char *fa_core_name(void) { return "hip-gfx950"; }
 
+/* one process per GPU: bind this process's coder to a device of the node */
+extern "C" int fiasco_amd_set_device(int device)
+{
+    if (hipSetDevice(device) != hipSuccess) {
+        fa_set_error("libfiasco_amd: cannot select HIP device %d", device);
+        return 0;
+    }
+    return 1;
+}
+
 #define HIPCK(call)                                                                        \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
@@ -334,6 +344,8 @@ extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)
                 g_stats.bytes_gram += F.bytes_gram;
                 g_stats.n_mp += F.n_mp; g_stats.n_steps += F.n_steps; g_stats.n_blocks += F.n_blocks;
                 g_stats.n_appends += F.n_appends; g_stats.n_fulleval += F.n_fulleval;
+                g_stats.t_init += F.t_init; g_stats.t_approx += F.t_approx; g_stats.t_ipis += F.t_ipis;
+                g_stats.t_append += F.t_append; g_stats.t_serial += F.t_serial; g_stats.t_total += F.t_total;
             } else {
                 const char *msg = "device coder failed";
                 if (F.status == FC_ERR_STATES) msg = "Maximum number of states reached!";

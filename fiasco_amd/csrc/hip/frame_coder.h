@@ -59,6 +59,8 @@ typedef struct DevFrame {
     /* ---- counters for the roofline model ---- */
     unsigned long long bytes_mp, bytes_img, bytes_gram;
     unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
+    /* ---- time per phase in 100 MHz wall-clock ticks (lane 0) ---- */
+    unsigned long long t_init, t_approx, t_ipis, t_append, t_serial, t_total;
     /* ---- optional per-call trace (FIASCO_AMD_TRACE), compared with the oracle's ---- */
     struct FcTrace *trace;
     int      trace_cap, trace_n;

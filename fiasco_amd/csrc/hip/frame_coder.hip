@@ -1015,10 +1015,12 @@ __global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
         sh.sp = 0;
         serial_advance(F, sh);
     }
+    unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_begin = wall_clock64();
     for (;;) {
         __syncthreads();
         const int op = sh.op;
         if (op == OP_DONE) break;
+        unsigned long long t0 = wall_clock64();
         switch (op) {
         case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1); break;
         case OP_APPROX:     op_approx(F, sh); break;
@@ -1026,7 +1028,17 @@ __global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
         }
         __syncthreads();
-        if (tid == 0) serial_advance(F, sh);
+        if (tid == 0) {
+            unsigned long long t1 = wall_clock64();
+            tk[op] += t1 - t0;
+            serial_advance(F, sh);
+            tk[0] += wall_clock64() - t1;
+        }
+    }
+    if (tid == 0) {
+        F.t_serial = tk[0]; F.t_init = tk[OP_INIT_RANGE]; F.t_approx = tk[OP_APPROX];
+        F.t_ipis = tk[OP_IPIS_INCR]; F.t_append = tk[OP_APPEND];
+        F.t_total = wall_clock64() - t_begin;
     }
     if (tid == 0) {
         const Range &rg = sh.st[0].rg;

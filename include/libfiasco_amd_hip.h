@@ -22,6 +22,10 @@ typedef struct fiasco_amd_stats {
      *   bytes_gram = sum over appended states of 4*(NL-1)*(s+1)*(1+E) + 8*NL*(s+1)        */
     unsigned long long bytes_mp, bytes_img, bytes_gram;
     unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
+    /* per-phase time summed over frames, 100 MHz ticks of workgroup lane 0:
+     * init_range, matching pursuit, incremental <block,state> tables, state append
+     * (images + Gram rows), serial partition-search bookkeeping, whole frame */
+    unsigned long long t_init, t_approx, t_ipis, t_append, t_serial, t_total;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);
@@ -31,6 +35,10 @@ void fiasco_amd_reset_stats(void);
  * "oracle-cpu" for the test-only oracle library (reference seam: codec/approx.h:24-27,
  * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */
 const char *fa_core_name(void);
+
+/* Select the HIP device this process encodes on (one process per GPU; default 0).
+ * Returns 1 on success, 0 + error message otherwise. */
+int fiasco_amd_set_device(int device);
 
 #ifdef __cplusplus
 }

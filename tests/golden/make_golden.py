@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors of tests/golden/ with the REAL reference coder.
+
+Runs only in the build container (needs oracle/_ref/cfiasco_ref built by
+oracle/ref_build.sh from /root/reference).  For every case it synthesises the input
+(tests/synth.py), runs the reference CLI and records:
+    small cases : input PNM + reference .fco committed as files
+    large cases : md5 + size of input and of the reference .fco (inputs are re-synthesised
+                  by the tests and verified against the recorded md5 before use)
+Output: tests/golden/MANIFEST.json + tests/golden/*.pgm|ppm|fco
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "cfiasco_ref")
+TMP = "/tmp/fiasco_golden"
+
+INPUTS = {
+    # name: (kind, args, commit_file)
+    "g96x64":   ("synth", dict(w=96, h=64, seed=5), True),
+    "g64x32":   ("synth", dict(w=64, h=32, seed=6), True),
+    "g32x32":   ("synth", dict(w=32, h=32, seed=8), True),
+    "g160x120": ("synth", dict(w=160, h=120, seed=7), True),
+    "g256":     ("synth", dict(w=256, h=256, seed=1234), True),
+    "n128x96":  ("noise", dict(w=128, h=96, seed=7), True),
+    "f0_96x64": ("synth", dict(w=96, h=64, seed=21), True),
+    "f1_96x64": ("synth", dict(w=96, h=64, seed=22), True),
+    "n512":     ("noise", dict(w=512, h=384, seed=7), False),
+    "g720":     ("synth", dict(w=1280, h=720, seed=1234), False),
+    "g1080":    ("synth", dict(w=1920, h=1080, seed=1234), False),
+    "c00":      ("color_c", dict(w=320, h=256, f=0), False),
+}
+
+CASES = [
+    # (case name, [input names], extra CLI args)
+    ("g32x32_q20", ["g32x32"], []),
+    ("g64x32_q20", ["g64x32"], []),
+    ("g96x64_q20", ["g96x64"], []),
+    ("g160x120_q20", ["g160x120"], []),
+    ("g256_q20", ["g256"], []),
+    ("g256_q5", ["g256"], ["-q", "5"]),
+    ("g256_q60", ["g256"], ["-q", "60"]),
+    ("g256_z1", ["g256"], ["-z", "1"]),
+    ("g256_z2", ["g256"], ["-z", "2"]),
+    ("g256_dict64", ["g256"], ["--dictionary-size", "64"]),
+    ("g256_rpf", ["g256"], ["--rpf-mantissa", "4", "--rpf-range", "2.0", "--dc-rpf-mantissa", "4"]),
+    ("g256_title", ["g256"], ["-t", "a title", "-c", "a comment"]),
+    ("n128x96_q20", ["n128x96"], []),
+    ("n128x96_q60", ["n128x96"], ["-q", "60"]),
+    ("n128x96_z1", ["n128x96"], ["-z", "1"]),
+    ("n128x96_z2", ["n128x96"], ["-z", "2"]),
+    ("seq2_gray_i", ["f0_96x64", "f1_96x64"], ["--pattern", "i"]),
+    ("n512_q20", ["n512"], []),
+    ("n512_z1", ["n512"], ["-z", "1"]),
+    ("n512_z2", ["n512"], ["-z", "2"]),
+    ("n512_q5_z1", ["n512"], ["-q", "5", "-z", "1"]),
+    ("g720_q20", ["g720"], []),
+    ("g1080_q20", ["g1080"], []),
+    ("c00_q20", ["c00"], []),
+    ("c00_z1", ["c00"], ["-z", "1"]),
+]
+
+
+def make_input(name):
+    kind, a, _ = INPUTS[name]
+    if kind == "synth":
+        return synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"])), "pgm"
+    if kind == "noise":
+        return synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"])), "pgm"
+    if kind == "color_c":
+        return synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"])), "ppm"
+    raise ValueError(kind)
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("reference CLI missing: run oracle/ref_build.sh first")
+    os.makedirs(TMP, exist_ok=True)
+    man = {"generator": "tests/golden/make_golden.py",
+           "reference": "l-tamas/Fiasco (FIASCO 1.3) built by oracle/ref_build.sh: gcc -O2 -fcommon",
+           "inputs": {}, "cases": []}
+    paths = {}
+    for name, (kind, a, commit) in INPUTS.items():
+        data, ext = make_input(name)
+        p = os.path.join(TMP, name + "." + ext)
+        open(p, "wb").write(data)
+        paths[name] = p
+        ent = {"kind": kind, "args": a, "md5": hashlib.md5(data).hexdigest(), "bytes": len(data),
+               "ext": ext, "file": None}
+        if commit:
+            ent["file"] = name + "." + ext
+            open(os.path.join(HERE, ent["file"]), "wb").write(data)
+        man["inputs"][name] = ent
+    env = dict(os.environ, FIASCO_DATA="/root/reference/data")
+    for cname, ins, args in CASES:
+        out = os.path.join(TMP, cname + ".fco")
+        cmd = [REF, "--progress-meter", "0"] + args + ["-o", out] + [paths[i] for i in ins]
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            sys.exit("reference failed on %s: %s" % (cname, r.stderr.decode()))
+        data = open(out, "rb").read()
+        ent = {"name": cname, "inputs": ins, "args": args, "md5": hashlib.md5(data).hexdigest(),
+               "bytes": len(data), "file": None}
+        if all(INPUTS[i][2] for i in ins):
+            ent["file"] = cname + ".fco"
+            open(os.path.join(HERE, ent["file"]), "wb").write(data)
+        man["cases"].append(ent)
+        print("%-16s %6d B  %s" % (cname, len(data), ent["md5"]))
+    json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

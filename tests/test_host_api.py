@@ -1,0 +1,167 @@
+"""Host-side behaviour of the C API: options object, error convention, exports.
+
+These mirror the rules of reference codec/options.c:139-708 and codec/coder.c:85-182
+(return 1 = ok, 0 = failure + fiasco_get_error_message()).  No compute on a GPU here.
+"""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import fiasco_amd
+
+
+def test_library_exports_every_declared_symbol(product):
+    for name in fiasco_amd.EXPORTED_SYMBOLS:
+        assert hasattr(product.L, name), name
+
+
+def test_headers_and_symbol_list_agree():
+    """Every function declared in include/*.h is in EXPORTED_SYMBOLS (and so checked above)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    decl = set()
+    for h in ("libfiasco_amd.h", "libfiasco_amd_hip.h"):
+        src = open(os.path.join(root, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        decl |= set(re.findall(r"\b((?:fiasco_|fa_core_|open_file)\w*)\s*\(", src))
+    decl -= {"fiasco_c_options"}
+    assert decl <= set(fiasco_amd.EXPORTED_SYMBOLS), decl - set(fiasco_amd.EXPORTED_SYMBOLS)
+
+
+def test_no_oracle_in_product():
+    """The product library must not link or contain the CPU oracle."""
+    out = subprocess.run(["nm", "-D", fiasco_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "fa_core_encode_frames" in out
+    dump = open(fiasco_amd.LIB_PATH, "rb").read()
+    assert b"oracle-cpu" not in dump and b"oracle_core" not in dump
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "fiasco_amd")):
+        for f in files:
+            if f.endswith(".py") or f == "Makefile":       # build recipes and python plumbing
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt, f
+            elif f.endswith((".c", ".cpp", ".hip")):        # sources: no include / link of it
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "oracle_core" not in txt, f
+
+
+def test_option_validation_messages(product):
+    o = product.c_options_new()
+    cases = [
+        ("set_optimizations", (6, 10, 3, 0, 0), "Size of dictionary has to be a positive number."),
+        ("set_optimizations", (6, 10, 0, 100, 0), "At least one dictionary element has to be used in an approximation."),
+        ("set_optimizations", (6, 3, 3, 100, 0), "Maximum image block size has to be at least level 4."),
+        ("set_optimizations", (3, 10, 3, 100, 0), "Minimum image block size has to be at least level 4."),
+        ("set_optimizations", (8, 6, 3, 100, 0), "Maximum block size has to be larger or equal minimum block size."),
+        ("set_prediction", (0, 6, 5), "Maximum prediction block size has to be at least level 6"),
+        ("set_quantization", (1, 1, 5, 1), "Number of RPF mantissa bits `1', `5' have to be in the interval [2,8]."),
+        ("set_quantization", (3, 7, 5, 1), "Invalid RPF ranges `7', `1' specified."),
+        ("set_chroma_quality", (2.0, 0), "Size of chroma compression dictionary has to be a positive number."),
+        ("set_chroma_quality", (0.0, 40), "Quality of chroma channel compression has to be positive value."),
+        ("set_frame_pattern", ("ipx",), "Frame type pattern contains invalid character `x' (choose I, B or P)."),
+        ("set_frame_pattern", ("",), "Frame type pattern doesn't contain any character."),
+        ("set_smoothing", (101,), "Smoothing percentage must be in the range [-1, 100]."),
+        ("set_progress_meter", (7,), "Invalid progress meter `7' specified (valid values are 0, 1, or 2)."),
+        ("set_tiling", (9, 4), "Invalid tiling method `9' specified (valid methods are 0, 1, 2, or 3)."),
+        ("set_basisfile", ("/nonexistent/basis.fco",), None),
+    ]
+    for name, args, msg in cases:
+        with pytest.raises(fiasco_amd.FiascoError) as e:
+            getattr(o, name)(*args)
+        if msg is not None:
+            assert str(e.value) == msg
+    # valid calls return 1
+    assert o.set_optimizations(6, 10, 3, 10000, 0) == 1
+    assert o.set_title("t") == 1 and o.set_comment("c") == 1
+    o.delete()
+
+
+def test_wrong_options_object_is_rejected(product):
+    """cast_c_options(): the private pointer must carry the COFIASCO tag (options.c:682-708)."""
+    class Fake(ctypes.Structure):
+        _fields_ = [("fn", ctypes.c_void_p * 13), ("private", ctypes.c_void_p)]
+    buf = ctypes.create_string_buffer(b"NOTFIASCO" + b"\0" * 64)
+    fake = Fake()
+    fake.private = ctypes.cast(buf, ctypes.c_void_p)
+    rc = product.L.fiasco_c_options_set_smoothing(ctypes.byref(fake), 70)
+    assert rc == 0
+    assert product.error_message() == "Parameter `options' doesn't match required type."
+
+
+def test_coder_parameter_errors(product, tmp_path):
+    o = product.cli_options()
+    assert product.fiasco_coder([str(tmp_path / "missing.pgm")], str(tmp_path / "o.fco"), 20.0, o) == 0
+    assert "Can't open frame" in product.error_message()
+    assert product.fiasco_coder(["x.pgm"], str(tmp_path / "o.fco"), 0.0, o) == 0
+    assert product.error_message() == "Compression quality has to be positive."
+    bad = tmp_path / "bad.pgm"
+    bad.write_bytes(b"P3\n32 32\n255\n" + b"0" * 100)
+    assert product.fiasco_coder([str(bad)], str(tmp_path / "o.fco"), 20.0, o) == 0
+    assert "image format 'P3' not supported" in product.error_message()
+    small = tmp_path / "small.pgm"
+    small.write_bytes(b"P5\n16 16\n255\n" + bytes(256))
+    assert product.fiasco_coder([str(small)], str(tmp_path / "o.fco"), 20.0, o) == 0
+    assert "has to be at least 32 pixels" in product.error_message()
+    odd = tmp_path / "odd.pgm"
+    odd.write_bytes(b"P5\n33 32\n255\n" + bytes(33 * 32))
+    assert product.fiasco_coder([str(odd)], str(tmp_path / "o.fco"), 20.0, o) == 0
+    assert product.error_message() == "Width and height of images must be even numbers."
+    o.delete()
+
+
+def test_limits_extension_api(product):
+    assert product.get_limits() == (6000, 22)          # stock MAXSTATES / MAXLEVEL
+    product.set_limits(30000, 26)
+    assert product.get_limits() == (30000, 26)
+    with pytest.raises(fiasco_amd.FiascoError):
+        product.set_limits(8, 22)
+    product.set_limits(6000, 22)
+
+
+def test_4k_needs_the_declared_limits_extension(product, tmp_path):
+    """The stock reference cannot code level-24 images (SURVEY finding 2); this library
+    reports it instead of crashing."""
+    p = tmp_path / "k.pgm"
+    p.write_bytes(b"P5\n3840 2160\n255\n" + bytes(3840 * 2160))
+    o = product.cli_options()
+    assert product.fiasco_coder([str(p)], str(tmp_path / "k.fco"), 20.0, o) == 0
+    assert "exceeds MAXLEVEL 22" in product.error_message()
+    o.delete()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_product_fails_loudly_without_gpu(product, inputs, tmp_path):
+    """No CPU fallback: without a HIP device the hot path refuses to run."""
+    o = product.cli_options()
+    rc = product.fiasco_coder([inputs.path("g96x64")], str(tmp_path / "o.fco"), 20.0, o)
+    assert rc == 0
+    assert "no HIP device available" in product.error_message()
+    out = product.encode_batch([inputs.data("g96x64")], 20.0, o)
+    assert out == [None]
+    o.delete()
+
+
+def test_input_template_expansion(oracle, inputs, tmp_path):
+    """prefix[start-end]suffix templates (codec/coder.c:390-488) == explicit name list."""
+    import shutil
+    shutil.copy(inputs.path("f0_96x64"), tmp_path / "fr0.pgm")
+    shutil.copy(inputs.path("f1_96x64"), tmp_path / "fr1.pgm")
+    o = oracle.cli_options(pattern="i")
+    assert oracle.fiasco_coder([str(tmp_path / "fr[0-1].pgm")], str(tmp_path / "a.fco"), 20.0, o) == 1
+    assert oracle.fiasco_coder([str(tmp_path / "fr0.pgm"), str(tmp_path / "fr1.pgm")],
+                               str(tmp_path / "b.fco"), 20.0, o) == 1
+    assert (tmp_path / "a.fco").read_bytes() == (tmp_path / "b.fco").read_bytes()
+    o.delete()
+
+
+def test_unsupported_modes_are_errors_not_silence(oracle, inputs, tmp_path):
+    o = oracle.cli_options()            # default pattern ippppppppp -> 2nd frame is a P frame
+    rc = oracle.fiasco_coder([inputs.path("f0_96x64"), inputs.path("f1_96x64")],
+                             str(tmp_path / "v.fco"), 20.0, o)
+    assert rc == 0 and "P/B frames" in oracle.error_message()
+    o.set_prediction(1, 6, 10)
+    rc = oracle.fiasco_coder([inputs.path("f0_96x64")], str(tmp_path / "v.fco"), 20.0, o)
+    assert rc == 0 and "prediction" in oracle.error_message()
+    o.delete()

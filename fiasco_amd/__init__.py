@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "fiasco_c_options_set_title", "fiasco_calloc", "open_file", "fiasco_amd_set_limits",
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
+    "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
+    "fiasco_amd_release_memory",
 ]
 
 
@@ -48,7 +50,8 @@ class Stats(ctypes.Structure):
                 ("n_fulleval", ctypes.c_ulonglong), ("t_init", ctypes.c_ulonglong),
                 ("t_approx", ctypes.c_ulonglong), ("t_ipis", ctypes.c_ulonglong),
                 ("t_append", ctypes.c_ulonglong), ("t_serial", ctypes.c_ulonglong),
-                ("t_total", ctypes.c_ulonglong)]
+                ("t_total", ctypes.c_ulonglong), ("t_mpA", ctypes.c_ulonglong),
+                ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):
@@ -186,6 +189,47 @@ class Library:
             else:
                 res.append(None)
         return res
+
+
+class Batch:
+    """Staged batch (fiasco_amd_batch_stage / _encode / _free): inputs stay resident in HBM
+    between encode() calls."""
+
+    def __init__(self, lib, pnm_list, quality=20.0, options=None):
+        c = ctypes
+        L = lib.L
+        L.fiasco_amd_batch_stage.argtypes = [c.c_uint, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t),
+                                             c.c_float, c.c_void_p]
+        L.fiasco_amd_batch_stage.restype = c.c_void_p
+        L.fiasco_amd_batch_encode.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]
+        L.fiasco_amd_batch_encode.restype = c.c_int
+        L.fiasco_amd_batch_free.argtypes = [c.c_void_p]
+        self.lib = lib
+        self.n = len(pnm_list)
+        bufs = (c.c_char_p * self.n)(*pnm_list)
+        lens = (c.c_size_t * self.n)(*[len(b) for b in pnm_list])
+        self.handle = L.fiasco_amd_batch_stage(self.n, bufs, lens, c.c_float(quality),
+                                               options.handle if options else None)
+        if not self.handle:
+            raise FiascoError(lib.error_message())
+
+    def encode(self):
+        outs = (ctypes.c_void_p * self.n)()
+        olen = (ctypes.c_size_t * self.n)()
+        self.lib.L.fiasco_amd_batch_encode(self.handle, outs, olen)
+        res = []
+        for i in range(self.n):
+            if outs[i]:
+                res.append(ctypes.string_at(outs[i], olen[i]))
+                self.lib.L.fiasco_amd_free(outs[i])
+            else:
+                res.append(None)
+        return res
+
+    def free(self):
+        if self.handle:
+            self.lib.L.fiasco_amd_batch_free(self.handle)
+            self.handle = None
 
 
 class COptions:

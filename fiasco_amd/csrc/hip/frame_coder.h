@@ -16,16 +16,19 @@
  *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
  *    num/den/est [P], ipdo [MAXED][P], used [P]   matching-pursuit scratch
  *    tree [2][P] i16, into [2][6][P] i16, weight [2][6][P] f32, ...  automaton, SoA
+ *  Nothing in the slab needs host-side initialisation: the kernel writes every cell before
+ *  it reads it (the basis automaton travels inside DevFrame).
  */
 #ifndef FRAME_CODER_H
 #define FRAME_CODER_H
 #include <stdint.h>
 
-#define FC_MAXED   5
-#define FC_BLOCK   256          /* threads per frame workgroup */
+#define FC_MAXED    5
+#define FC_BLOCK    256         /* threads per frame workgroup */
 #define FC_MAXDEPTH 22          /* recursion depth bound: level <= 26, lc_min >= 6 */
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS */
 #define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
+#define FC_MAXBASIS 16          /* states of the initial basis */
 
 enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5 };
 
@@ -42,6 +45,12 @@ typedef struct DevFrame {
     int      NL, NS, NA, NI;
     int      coeff_size, coeff_nt, dcs, sy;
     int      basis_states;
+    /* ---- initial basis automaton (codec/wfa.h:112-138 rows of the basis states) ---- */
+    int16_t  b_tree[FC_MAXBASIS][2];
+    int16_t  b_into[FC_MAXBASIS][2][6];
+    float    b_weight[FC_MAXBASIS][2][6];
+    float    b_final[FC_MAXBASIS];
+    uint8_t  b_dtype[FC_MAXBASIS];
     /* ---- tables ---- */
     const int16_t *pix16;
     float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;
@@ -61,6 +70,7 @@ typedef struct DevFrame {
     unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
     /* ---- time per phase in 100 MHz wall-clock ticks (lane 0) ---- */
     unsigned long long t_init, t_approx, t_ipis, t_append, t_serial, t_total;
+    unsigned long long t_mpA, t_mpB, n_blockevals;
     /* ---- optional per-call trace (FIASCO_AMD_TRACE), compared with the oracle's ---- */
     struct FcTrace *trace;
     int      trace_cap, trace_n;

@@ -81,22 +81,32 @@ struct MPState {
     int   b_index;
 };
 
+/* aac model (coeff.c:190-208): totals first, then the counts, one 16-byte aligned block so
+ * that a snapshot is a short run of 128-bit LDS copies */
+struct __attribute__((aligned(16))) CoeffBuf {
+    short tot[32];
+    short cnt[FC_MAXCOEFF];
+};
+#define SNAP_POOL16 928            /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
+#define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
+
 struct Sh {
     SFrame   st[FC_MAXDEPTH];
     int      sp;
     int      op, a0, a1, a2, a3;
     Pool     pool;
-    short    coeff[FC_MAXCOEFF];
-    short    coeff_tot[32];
-    short    snap_coeff[FC_MAXDEPTH][2][FC_MAXCOEFF + 32];
-    unsigned tm[4 * 26 + 8];
-    unsigned snap_tm[FC_MAXDEPTH][4 * 26];
+    CoeffBuf cb;
+    uint4    snap_pool[SNAP_POOL16];
+    int      n16;                  /* uint4 per aac snapshot */
+    __attribute__((aligned(16))) unsigned tm[TM_WORDS];
+    __attribute__((aligned(16))) unsigned snap_tm[FC_MAXDEPTH][TM_WORDS];
     float    m0tab[12];
     double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM];
     float    Ltab[MAXED + 1];
     float    Q0, Q1;
     MPState  mp;
-    float    blockmin[512];
+    float    blockmin[NBLOCKMIN];
     float    pixels[1024];
     int      states;               /* wfa->states */
     int      failed;
@@ -259,29 +269,56 @@ __device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int l
         int cnt = 1 << delta;
         int slot0 = ((image + 1) << delta) - 1;
         int adr0 = address << delta;
+        const float *src0 = (lv == il + 1) ? F.d5 + (size_t) (adr0 * 2) * P
+                                           : F.ipis + (size_t) (slot0 * 2 + 1) * P;
         for (int s = from + tid; s < states; s += B) {
             if (!F.domain_type[s]) continue;
-            int kid[2], ne[2], ed[2][MAXED + 1];
-            float ew[2][MAXED + 1];
+            /* term list of the state: per label the tree child (weight 1, added plain) and
+             * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
+             * of a group of slots are in flight together (the chain is latency bound). */
+            int   idx[2][MAXED + 1];
+            float wt[2][MAXED + 1];
+            unsigned msk[2];
+#pragma unroll
             for (int l = 0; l < 2; l++) {
-                kid[l] = TREE(F, s, l);
-                int e = 0, d;
-                for (; (d = INTO(F, s, l, e)) != NOEDGE; e++) { ed[l][e] = d; ew[l][e] = WEIGHT(F, s, l, e); }
-                ne[l] = e;
-            }
-            for (int j = 0; j < cnt; j++) {
-                float acc = 0;
-                for (int l = 0; l < 2; l++) {
-                    const float *src = (lv == il + 1)
-                        ? F.d5 + (size_t) ((adr0 + j) * 2 + l) * P
-                        : F.ipis + (size_t) ((slot0 + j) * 2 + l + 1) * P;
-                    if (kid[l] != RANGE_) acc += src[kid[l]];
-                    for (int e = 0; e < ne[l]; e++) {
-                        if (lv == il + 1) acc += ew[l][e] * src[ed[l][e]];
-                        else              acc += src[ed[l][e]] * ew[l][e];
-                    }
+                int k = TREE(F, s, l);
+                msk[l] = k != RANGE_ ? 1u : 0u;
+                idx[l][0] = k != RANGE_ ? k : 0;
+                wt[l][0] = 1.0f;
+                bool live = true;
+#pragma unroll
+                for (int e = 0; e < MAXED; e++) {
+                    int d = live ? INTO(F, s, l, e) : NOEDGE;
+                    live = live && d != NOEDGE;
+                    idx[l][e + 1] = live ? d : 0;
+                    wt[l][e + 1] = live ? WEIGHT(F, s, l, e) : 0.0f;
+                    msk[l] |= live ? (2u << e) : 0u;
                 }
-                F.ipis[(size_t) (slot0 + j) * P + s] = acc;
+            }
+            for (int j0 = 0; j0 < cnt; j0 += 4) {
+                float v[4][2][MAXED + 1];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                    for (int l = 0; l < 2; l++)
+#pragma unroll
+                        for (int i = 0; i <= MAXED; i++) {
+                            bool on = ((msk[l] >> i) & 1u) && j0 + jj < cnt;
+                            v[jj][l][i] = on ? src0[(size_t) ((j0 + jj) * 2 + l) * P + idx[l][i]] : 0.0f;
+                        }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    if (j0 + jj >= cnt) break;
+                    float acc = 0;
+#pragma unroll
+                    for (int l = 0; l < 2; l++) {
+                        if (msk[l] & 1u) acc += v[jj][l][0];
+#pragma unroll
+                        for (int i = 1; i <= MAXED; i++)
+                            if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
+                    }
+                    F.ipis[(size_t) (slot0 + j0 + jj) * P + s] = acc;
+                }
             }
         }
         __syncthreads();
@@ -450,10 +487,10 @@ __device__ void mp_tables(const DevFrame &F, Sh &sh, int level)
 {
     const int tid = threadIdx.x;
     if (tid < F.dcs)
-        sh.lgdc[tid] = log2((double) (sh.coeff[tid] / (float) sh.coeff_tot[0]));
+        sh.lgdc[tid] = log2((double) (sh.cb.cnt[tid] / (float) sh.cb.tot[0]));
     else if (tid >= 64 && tid < 64 + F.sy) {
         int sym = tid - 64, ctx = level - F.lc_min;
-        sh.lglv[sym] = log2((double) (sh.coeff[F.dcs + ctx * F.sy + sym] / (float) sh.coeff_tot[ctx + 1]));
+        sh.lglv[sym] = log2((double) (sh.cb.cnt[F.dcs + ctx * F.sy + sym] / (float) sh.cb.tot[ctx + 1]));
     } else if (tid >= 128 && tid < 128 + MAXED + 1)
         sh.Ltab[tid - 128] = (float) -log2((double) (sh.pool.count[tid - 128] / (float) sh.pool.total));
     else if (tid == 192) {
@@ -510,11 +547,11 @@ __device__ void models_update(const DevFrame &F, Sh &sh, const short *indices, c
     int ctx = level - F.lc_min;
     for (int e = 0; into[e] != NOEDGE; e++)
         if (into[e]) {
-            sh.coeff[F.dcs + ctx * F.sy + rtob_dev(weight[e], F.rpf_mant, F.rpf_range)]++;
-            sh.coeff_tot[ctx + 1]++;
+            sh.cb.cnt[F.dcs + ctx * F.sy + rtob_dev(weight[e], F.rpf_mant, F.rpf_range)]++;
+            sh.cb.tot[ctx + 1]++;
         } else {
-            sh.coeff[rtob_dev(weight[e], F.dc_mant, F.dc_range)]++;
-            sh.coeff_tot[0]++;
+            sh.cb.cnt[rtob_dev(weight[e], F.dc_mant, F.dc_range)]++;
+            sh.cb.tot[0]++;
         }
 }
 
@@ -555,56 +592,92 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
     __syncthreads();
 
     const int nblk = (D + 63) >> 6;
+    constexpr int U = 4;                 /* candidates per lane per pass: loads of all U in flight */
+    unsigned long long tA = 0, tB = 0, tmark = wall_clock64();
+    unsigned blockevals = 0;
     for (;;) {
         const int n = mp.n;
         /* ---------------- phase A: Gram-Schmidt update + stage-1 estimate ---------------- */
         {
             const float *Grow = n ? GRAM(F, q) + (size_t) mp.row_state * P : nullptr;
+            const float *diag = F.diag + (size_t) q * P;
+            const float *numrow = F.ipis + (size_t) mp.image * P;
             const int nv = n - 1;
             float novk[MAXED], selk[MAXED], nov_nv = 1, ipio_nv = 0;
             for (int k = 0; k < nv; k++) { novk[k] = mp.norm_ov[k]; selk[k] = mp.sel_ipdo[nv][k]; }
             if (n) { nov_nv = mp.norm_ov[nv]; ipio_nv = mp.ipio[nv]; }
-            for (int base = 0; base < nblk * 64; base += B) {
-                int d = base + tid;
-                float e = BIGF;
-                if (d < D) {
-                    int s = F.pool_states[d];
-                    bool u;
-                    float num = 0, den = 1;
-                    if (n == 0) {
-                        den = F.diag[(size_t) q * P + s];
-                        u = den / size < MIN_NORM;
-                        if (!u) {
-                            num = F.ipis[(size_t) mp.image * P + s];
-                            u = fabsf(num) < MIN_NORM;
-                        }
-                        F.num[d] = num; F.den[d] = den; F.used[d] = u;
-                    } else {
-                        u = F.used[d];
-                        if (!u) {
-                            num = F.num[d]; den = F.den[d];
-                            float t = Grow[s];
-                            for (int k = 0; k < nv; k++)
-                                t -= F.ipdo[(size_t) k * P + d] / novk[k] * selk[k];
-                            F.ipdo[(size_t) nv * P + d] = t;
-                            den -= t * t / nov_nv;
-                            num -= ipio_nv / nov_nv * t;
-                            if (den / size < MIN_NORM) { u = true; F.used[d] = 1; }
-                            F.num[d] = num; F.den[d] = den;
-                        }
-                    }
-                    if (!u) e = stage1(sh, d, s, num, den);
-                    F.est[d] = e;
+            for (int base = 0; base < nblk * 64; base += B * U) {
+                int dd[U], ss[U];
+                bool in[U], us[U];
+                float num[U], den[U], g[U], ip[U][MAXED - 1], e[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    dd[u] = base + u * B + tid;
+                    in[u] = dd[u] < D;
+                    ss[u] = in[u] ? F.pool_states[dd[u]] : 0;
+                    us[u] = (in[u] && n) ? F.used[dd[u]] != 0 : !in[u];
                 }
-                float bm = wave_min(e);
-                if (lane == 0 && (base >> 6) + wave < 512) sh.blockmin[(base >> 6) + wave] = bm;
+                if (n == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        den[u] = in[u] ? diag[ss[u]] : 1.0f;
+                        num[u] = in[u] ? numrow[ss[u]] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (!in[u]) continue;
+                        bool uu = den[u] / size < MIN_NORM;
+                        if (!uu) uu = fabsf(num[u]) < MIN_NORM;
+                        us[u] = uu;
+                        F.num[dd[u]] = num[u]; F.den[dd[u]] = den[u]; F.used[dd[u]] = uu;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        bool on = !us[u];
+                        num[u] = on ? F.num[dd[u]] : 0.0f;
+                        den[u] = on ? F.den[dd[u]] : 1.0f;
+                        g[u] = on ? Grow[ss[u]] : 0.0f;
+#pragma unroll
+                        for (int k = 0; k < MAXED - 1; k++)
+                            ip[u][k] = (on && k < nv) ? F.ipdo[(size_t) k * P + dd[u]] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (us[u]) continue;
+                        float t = g[u];
+#pragma unroll
+                        for (int k = 0; k < MAXED - 1; k++)
+                            if (k < nv) t -= ip[u][k] / novk[k] * selk[k];
+                        F.ipdo[(size_t) nv * P + dd[u]] = t;
+                        den[u] -= t * t / nov_nv;
+                        num[u] -= ipio_nv / nov_nv * t;
+                        if (den[u] / size < MIN_NORM) { us[u] = true; F.used[dd[u]] = 1; }
+                        F.num[dd[u]] = num[u]; F.den[dd[u]] = den[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    e[u] = BIGF;
+                    if (in[u]) {
+                        if (!us[u]) e[u] = stage1(sh, dd[u], ss[u], num[u], den[u]);
+                        F.est[dd[u]] = e[u];
+                    }
+                    float bm = wave_min(e[u]);
+                    int blk = ((base + u * B) >> 6) + wave;
+                    if (lane == 0 && blk < NBLOCKMIN) sh.blockmin[blk] = bm;
+                }
             }
         }
         __syncthreads();
-        /* ---------------- phase B: ordered replay (wave 0) ---------------- */
+        if (tid == 0) { unsigned long long t = wall_clock64(); tA += t - tmark; tmark = t; }
+        /* ------- phase B: ordered replay + commit of the step, all inside wave 0 ------- */
         if (wave == 0) {
             float m = mp.min_costs;
             unsigned evals = 0;
+            /* lane 0 keeps the best candidate of the step in registers */
+            int b_index = -1;
+            float b_cost = 0, b_mbits = 0, b_wbits = 0, b_err = 0, b_f[MAXED];
             for (int bb = 0; bb < nblk; bb += 64) {
                 float bm = (bb + lane < nblk) ? sh.blockmin[bb + lane] : BIGF;
                 int lastb = -1;
@@ -617,52 +690,56 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
                     float e = (d < D) ? F.est[d] : BIGF;
                     bool pass = e < m;
                     Eval ev;
-                    ev.costs = BIGF;
+                    ev.costs = BIGF; ev.m_bits = ev.w_bits = ev.m_err = 0;
+                    for (int k = 0; k < MAXED; k++) ev.f[k] = 0;
                     if (pass) full_eval(F, sh, d, F.pool_states[d], F.num[d], F.den[d], ev);
                     evals += (unsigned) __popcll(__ballot(pass));
-                    int last = -1;
+                    blockevals++;
+                    int last = -1, win = -1;
                     for (;;) {
                         unsigned long long ok = __ballot(pass && lane > last && e < m && ev.costs < m);
                         if (!ok) break;
                         int j = __ffsll((long long) ok) - 1;
-                        last = j;
+                        last = j; win = j;
                         m = __shfl(ev.costs, j);
-                        if (lane == j) {
-                            mp.b_index = d; mp.b_cost = ev.costs; mp.b_mbits = ev.m_bits;
-                            mp.b_wbits = ev.w_bits; mp.b_err = ev.m_err;
-                            for (int k = 0; k <= n; k++) mp.b_f[k] = ev.f[k];
-                        }
+                    }
+                    if (win >= 0) {                 /* wave-uniform */
+                        b_index = ((bb + jb) << 6) + win;
+                        b_cost = __shfl(ev.costs, win); b_mbits = __shfl(ev.m_bits, win);
+                        b_wbits = __shfl(ev.w_bits, win); b_err = __shfl(ev.m_err, win);
+#pragma unroll
+                        for (int k = 0; k < MAXED; k++) b_f[k] = __shfl(ev.f[k], win);
                     }
                 }
             }
-            if (lane == 0) F.n_fulleval += evals;
-        }
-        __syncthreads();
-        /* ---------------- commit (lane 0) ---------------- */
-        if (tid == 0) {
-            int index = mp.b_index;
-            if (index >= 0) {
-                if (mp.b_cost < mp.costs) {
-                    mp.costs = mp.b_cost; mp.err = mp.b_err;
-                    mp.matrix_bits = mp.b_mbits; mp.weights_bits = mp.b_wbits;
-                    for (int k = 0; k <= n; k++) mp.weight[k] = mp.b_f[k];
-                    mp.best_n = n + 1;
+            if (lane == 0) {
+                F.n_fulleval += evals;
+                int index = b_index;
+                if (index >= 0) {
+                    if (b_cost < mp.costs) {
+                        mp.costs = b_cost; mp.err = b_err;
+                        mp.matrix_bits = b_mbits; mp.weights_bits = b_wbits;
+                        for (int k = 0; k <= n; k++) mp.weight[k] = b_f[k];
+                        mp.best_n = n + 1;
+                    }
+                    mp.indices[n] = (short) index;
+                    mp.into[n] = F.pool_states[index];
+                    F.used[index] = 1;
+                    mp.norm_ov[n] = F.den[index];
+                    mp.ipio[n] = F.num[index];
+                    for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + index];
+                    mp.row_state = mp.into[n];
+                    mp.n = n + 1;
+                    if (mp.n < F.max_elements) mp_step_prepare(F, sh);
                 }
-                mp.indices[n] = (short) index;
-                mp.into[n] = F.pool_states[index];
-                F.used[index] = 1;
-                mp.norm_ov[n] = F.den[index];
-                mp.ipio[n] = F.num[index];
-                for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + index];
-                mp.row_state = mp.into[n];
-                mp.n = n + 1;
-                if (mp.n < F.max_elements) mp_step_prepare(F, sh);
+                mp.index = index;
             }
-            mp.index = index;
         }
         __syncthreads();
+        if (tid == 0) { unsigned long long t = wall_clock64(); tB += t - tmark; tmark = t; }
         if (!(mp.n < F.max_elements && mp.index >= 0)) break;
     }
+    if (tid == 0) { F.t_mpA += tA; F.t_mpB += tB; F.n_blockevals += blockevals; }
 
     if (tid == 0) {
         Range &lr = fr.lrange;
@@ -718,18 +795,30 @@ __device__ void tree_update_dev(Sh &sh, int ML, int child, int level, int which)
     counts[ML + level]++;
 }
 
+/* model snapshots: short runs of 128-bit LDS copies (lane 0) */
+__device__ __forceinline__ void copy16(uint4 *dst, const uint4 *src, int n)
+{
+    for (int i = 0; i < n; i++) dst[i] = src[i];
+}
+
 __device__ void snap_save(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    short *dst = sh.snap_coeff[depth][which];
-    for (int i = 0; i < F.coeff_size; i++) dst[i] = sh.coeff[i];
-    for (int i = 0; i < F.coeff_nt; i++) dst[FC_MAXCOEFF + i] = sh.coeff_tot[i];
+    copy16(sh.snap_pool + (depth * 2 + which) * sh.n16, (const uint4 *) &sh.cb, sh.n16);
 }
 
 __device__ void snap_load(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    const short *src = sh.snap_coeff[depth][which];
-    for (int i = 0; i < F.coeff_size; i++) sh.coeff[i] = src[i];
-    for (int i = 0; i < F.coeff_nt; i++) sh.coeff_tot[i] = src[FC_MAXCOEFF + i];
+    copy16((uint4 *) &sh.cb, sh.snap_pool + (depth * 2 + which) * sh.n16, sh.n16);
+}
+
+__device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML)
+{
+    copy16((uint4 *) sh.snap_tm[depth], (const uint4 *) sh.tm, ML);      /* 4*ML words */
+}
+
+__device__ __forceinline__ void tm_load(Sh &sh, int depth, int ML)
+{
+    copy16((uint4 *) sh.tm, (const uint4 *) sh.snap_tm[depth], ML);
 }
 
 /* wfalib.c:152-180 */
@@ -803,7 +892,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             Range &rg = fr.rg;
             fr.pool0 = sh.pool;
             snap_save(F, sh, sh.sp, 0);
-            for (int i = 0; i < 4 * ML; i++) sh.snap_tm[sh.sp][i] = sh.tm[i];
+            tm_save(sh, sh.sp, ML);
             fr.states = sh.states;
             fr.phase = PH_AFTER_LC;
             if (rg.level <= F.lc_max) {
@@ -903,14 +992,14 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             if (fr.lincomb >= MAXCOSTS && fr.subdiv >= MAXCOSTS) {
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sh.sp, 0);
-                for (int i = 0; i < 4 * ML; i++) sh.tm[i] = sh.snap_tm[sh.sp][i];
+                tm_load(sh, sh.sp, ML);
                 sh.states = fr.states;
                 fr.ret = MAXCOSTS;
                 goto pop;
             } else if (fr.lincomb < fr.subdiv) {
                 sh.pool = fr.pool_lc;
                 snap_load(F, sh, sh.sp, 1);
-                for (int i = 0; i < 4 * ML; i++) sh.tm[i] = sh.snap_tm[sh.sp][i];
+                tm_load(sh, sh.sp, ML);
                 rg = fr.lrange;
                 sh.states = fr.states;
                 fr.ret = fr.lincomb;
@@ -968,7 +1057,7 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
     sh.states = nb;
 }
 
-__global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
+__global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
 {
     __shared__ Sh sh;
     DevFrame &F = frames[blockIdx.x];
@@ -981,13 +1070,32 @@ __global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
         static const unsigned c0[22] = {20,17,15,10,5,4,3,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1};
         static const unsigned c1[22] = {1,1,1,1,1,1,1,1,1,2,3,5,10,15,20,25,30,35,60,60,60,60};
         sh.failed = 0;
+        /* a staged frame may be encoded several times: start from clean counters */
+        F.bytes_mp = F.bytes_img = F.bytes_gram = 0;
+        F.n_mp = F.n_steps = F.n_blocks = F.n_appends = F.n_fulleval = 0;
+        F.trace_n = 0;
+        F.t_mpA = F.t_mpB = F.n_blockevals = 0;
+        /* rows of the basis states (input/basis.c:61-114, input/read.c:219-340) */
+        for (int s = 0; s < F.basis_states; s++) {
+            F.final_d[s] = F.b_final[s];
+            F.domain_type[s] = F.b_dtype[s];
+            F.level_of_state[s] = 0xff;
+            for (int l = 0; l < 2; l++) {
+                TREE(F, s, l) = F.b_tree[s][l];
+                for (int e = 0; e < 6; e++) {
+                    INTO(F, s, l, e) = F.b_into[s][l][e];
+                    WEIGHT(F, s, l, e) = F.b_weight[s][l][e];
+                    if (F.b_into[s][l][e] == NOEDGE) break;
+                }
+            }
+        }
         for (int w = 0; w < 2; w++)
             for (int l = 0; l < ML; l++) {
                 int k = l < 22 ? l : 21;
                 sh.tm[w * 2 * ML + l] = c1[k];
                 sh.tm[w * 2 * ML + ML + l] = c0[k] + c1[k];
             }
-        for (int i = 4 * ML; i < 4 * 26 + 8; i++) sh.tm[i] = 0;
+        for (int i = 4 * ML; i < TM_WORDS; i++) sh.tm[i] = 0;
         /* rle pool over the usable basis states (domain-pool.c:632-676) */
         Pool &m = sh.pool;
         m.total = 0;
@@ -1000,9 +1108,13 @@ __global__ void __launch_bounds__(B) fiasco_frame_kernel(DevFrame *frames)
                 if (s == 0) m.d0_n = 1;
             }
         /* aac model, all-ones (coeff.c:297-310) */
-        for (int i = 0; i < F.coeff_size; i++) sh.coeff[i] = 1;
-        sh.coeff_tot[0] = (short) F.dcs;
-        for (int i = 1; i < F.coeff_nt; i++) sh.coeff_tot[i] = (short) F.sy;
+        sh.n16 = (64 + 2 * F.coeff_size + 15) / 16;
+        if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16) sh.failed = FC_ERR_INTERNAL;
+        for (int i = 0; i < FC_MAXCOEFF; i++) sh.cb.cnt[i] = 0;
+        for (int i = 0; i < 32; i++) sh.cb.tot[i] = 0;
+        for (int i = 0; i < F.coeff_size; i++) sh.cb.cnt[i] = 1;
+        sh.cb.tot[0] = (short) F.dcs;
+        for (int i = 1; i < F.coeff_nt; i++) sh.cb.tot[i] = (short) F.sy;
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
         SFrame &r = sh.st[0];

@@ -361,60 +361,103 @@ done:
 
 /* ---------------------------------------------------------------- public: batch */
 
+struct fiasco_amd_batch {
+    unsigned   n;
+    fa_job    *jobs;
+    fa_image **ims;
+    fa_info   *infos;
+    int        normal_domains, delta_domains;
+    void      *staged;        /* core handle: inputs resident where the core computes */
+};
+
+void fiasco_amd_batch_free(fiasco_amd_batch_t *b)
+{
+    unsigned i;
+    if (!b) return;
+    if (b->staged) fa_core_unstage(b->staged);
+    for (i = 0; i < b->n; i++) {
+        if (b->jobs && b->jobs[i].wfa) fa_wfa_free(b->jobs[i].wfa);
+        if (b->ims) fa_image_free(b->ims[i]);
+        if (b->infos) fa_info_free(&b->infos[i]);
+    }
+    free(b->jobs); free(b->ims); free(b->infos);
+    free(b);
+}
+
+fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *const *pnm,
+                                           const size_t *pnm_len, float quality,
+                                           const fiasco_c_options_t *options)
+{
+    fiasco_c_options_t *defaults = NULL;
+    const fa_options *op;
+    fiasco_amd_batch_t *b;
+    unsigned i;
+
+    if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return NULL; }
+    if (options) { op = fa_cast_options(options); if (!op) return NULL; }
+    else { defaults = fiasco_c_options_new(); if (!defaults) return NULL; op = fa_cast_options(defaults); }
+    if (op->prediction) {
+        fa_set_error("Intra prediction (ND) is not supported by this library build.");
+        if (defaults) fiasco_c_options_delete(defaults);
+        return NULL;
+    }
+    b = (fiasco_amd_batch_t *) calloc(1, sizeof *b);
+    b->n = n;
+    b->jobs  = (fa_job *) calloc(n ? n : 1, sizeof *b->jobs);
+    b->ims   = (fa_image **) calloc(n ? n : 1, sizeof *b->ims);
+    b->infos = (fa_info *) calloc(n ? n : 1, sizeof *b->infos);
+    b->normal_domains = op->normal_domains;
+    b->delta_domains  = op->delta_domains;
+    for (i = 0; i < n; i++) {
+        fa_cparams cp;
+        b->ims[i] = fa_image_from_pnm(pnm[i], pnm_len[i], "<memory>");
+        if (!b->ims[i] || !fa_setup_params(op, quality, b->ims[i]->width, b->ims[i]->height,
+                                          b->ims[i]->color, 1, &b->infos[i], &cp)
+            || !prepare_job(&b->jobs[i], b->ims[i], &cp, op->basis_name)) {
+            if (defaults) fiasco_c_options_delete(defaults);
+            fiasco_amd_batch_free(b);
+            return NULL;
+        }
+    }
+    if (defaults) fiasco_c_options_delete(defaults);
+    b->staged = fa_core_stage(n, b->jobs);
+    return b;
+}
+
+int fiasco_amd_batch_encode(fiasco_amd_batch_t *b, unsigned char **outv, size_t *out_len)
+{
+    unsigned i, good = 0;
+    if (!b) return 0;
+    for (i = 0; i < b->n; i++) { outv[i] = NULL; out_len[i] = 0; }
+    fa_core_run(b->staged);
+    for (i = 0; i < b->n; i++) {
+        fa_bitw out;
+        if (!b->jobs[i].status) { fa_set_error("%s", b->jobs[i].errmsg); continue; }
+        fa_bw_init(&out);
+        if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, 0, b->normal_domains,
+                           b->delta_domains, &out)) {
+            out_len[i] = fa_bw_finish(&out);
+            outv[i] = (unsigned char *) malloc(out_len[i]);
+            memcpy(outv[i], out.buf, out_len[i]);
+            good++;
+        }
+        fa_bw_free(&out);
+    }
+    return (int) good;
+}
+
 int fiasco_amd_encode_batch(unsigned n, const unsigned char *const *pnm, const size_t *pnm_len,
                             float quality, const fiasco_c_options_t *options,
                             unsigned char **outv, size_t *out_len)
 {
-    fiasco_c_options_t *defaults = NULL;
-    const fa_options *op;
-    fa_job *jobs;
-    fa_image **ims;
-    fa_info *infos;
-    unsigned i, good = 0;
-    int failed = 0;
-
-    if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return 0; }
-    if (options) { op = fa_cast_options(options); if (!op) return 0; }
-    else { defaults = fiasco_c_options_new(); if (!defaults) return 0; op = fa_cast_options(defaults); }
-    if (op->prediction) {
-        fa_set_error("Intra prediction (ND) is not supported by this library build.");
-        if (defaults) fiasco_c_options_delete(defaults);
+    unsigned i;
+    int good;
+    fiasco_amd_batch_t *b = fiasco_amd_batch_stage(n, pnm, pnm_len, quality, options);
+    if (!b) {
+        for (i = 0; i < n; i++) { outv[i] = NULL; out_len[i] = 0; }
         return 0;
     }
-    jobs  = (fa_job *) calloc(n ? n : 1, sizeof *jobs);
-    ims   = (fa_image **) calloc(n ? n : 1, sizeof *ims);
-    infos = (fa_info *) calloc(n ? n : 1, sizeof *infos);
-    for (i = 0; i < n; i++) { outv[i] = NULL; out_len[i] = 0; }
-    for (i = 0; i < n && !failed; i++) {
-        fa_cparams cp;
-        ims[i] = fa_image_from_pnm(pnm[i], pnm_len[i], "<memory>");
-        if (!ims[i]) { failed = 1; break; }
-        if (!fa_setup_params(op, quality, ims[i]->width, ims[i]->height, ims[i]->color, 1,
-                             &infos[i], &cp)) { failed = 1; break; }
-        if (!prepare_job(&jobs[i], ims[i], &cp, op->basis_name)) failed = 1;
-    }
-    if (!failed) {
-        fa_core_encode_frames(n, jobs);
-        for (i = 0; i < n; i++) {
-            fa_bitw out;
-            if (!jobs[i].status) { fa_set_error("%s", jobs[i].errmsg); continue; }
-            fa_bw_init(&out);
-            if (fa_write_frame(jobs[i].wfa, &infos[i], FA_I_FRAME, 0, 0, op->normal_domains,
-                               op->delta_domains, &out)) {
-                out_len[i] = fa_bw_finish(&out);
-                outv[i] = (unsigned char *) malloc(out_len[i]);
-                memcpy(outv[i], out.buf, out_len[i]);
-                good++;
-            }
-            fa_bw_free(&out);
-        }
-    }
-    for (i = 0; i < n; i++) {
-        if (jobs[i].wfa) fa_wfa_free(jobs[i].wfa);
-        fa_image_free(ims[i]);
-        fa_info_free(&infos[i]);
-    }
-    free(jobs); free(ims); free(infos);
-    if (defaults) fiasco_c_options_delete(defaults);
-    return (int) good;
+    good = fiasco_amd_batch_encode(b, outv, out_len);
+    fiasco_amd_batch_free(b);
+    return good;
 }

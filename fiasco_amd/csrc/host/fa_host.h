@@ -167,8 +167,14 @@ typedef struct fa_job {
                                            frame (colour carry, codec/coder.c:785-797) */
 } fa_job;
 
-/* THE SEAM.  Encode n independent frames.  Returns number of successful jobs. */
-int fa_core_encode_frames(unsigned n, fa_job *jobs);
+/* THE SEAM.  Encode n independent frames.  Returns number of successful jobs.
+ * Staged form: stage() makes the inputs resident where the core computes (HBM for the HIP
+ * core), run() encodes every staged frame (may be called repeatedly), unstage() releases.
+ * jobs[] must stay alive between stage() and unstage(). */
+int   fa_core_encode_frames(unsigned n, fa_job *jobs);
+void *fa_core_stage(unsigned n, fa_job *jobs);
+int   fa_core_run(void *staged);
+void  fa_core_unstage(void *staged);
 const char *fa_core_name(void);
 
 /* ---------------- bit writer (reference lib/bit-io.c, memory backed) -------------- */

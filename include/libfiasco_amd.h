@@ -120,6 +120,19 @@ int fiasco_amd_encode_batch(unsigned n, const unsigned char *const *pnm,
                             unsigned char **out, size_t *out_len);
 void fiasco_amd_free(void *p);
 
+/* Staged form of the batch encoder, for callers that keep frames resident on the GPU:
+ *   stage : parse the PNM buffers, upload the pixel planes into HBM        -> handle
+ *   encode: run the hot path over every staged frame and write the .fco byte strings
+ *           (same out/out_len contract as fiasco_amd_encode_batch); repeatable
+ *   free  : release the handle (HBM slabs go back to the library's pool)
+ * fiasco_amd_encode_batch(...) == stage + encode + free.                               */
+typedef struct fiasco_amd_batch fiasco_amd_batch_t;
+fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *const *pnm,
+                                           const size_t *pnm_len, float quality,
+                                           const fiasco_c_options_t *options);
+int  fiasco_amd_batch_encode(fiasco_amd_batch_t *batch, unsigned char **out, size_t *out_len);
+void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,9 @@ typedef struct fiasco_amd_stats {
      * init_range, matching pursuit, incremental <block,state> tables, state append
      * (images + Gram rows), serial partition-search bookkeeping, whole frame */
     unsigned long long t_init, t_approx, t_ipis, t_append, t_serial, t_total;
+    /* inside matching pursuit: candidate-parallel phase, ordered-replay phase (ticks); number
+     * of 64-candidate blocks whose survivors were fully evaluated */
+    unsigned long long t_mpA, t_mpB, n_blockevals;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);
@@ -39,6 +42,10 @@ const char *fa_core_name(void);
 /* Select the HIP device this process encodes on (one process per GPU; default 0).
  * Returns 1 on success, 0 + error message otherwise. */
 int fiasco_amd_set_device(int device);
+
+/* The launcher keeps the per-frame HBM slabs of finished calls in a process-wide pool
+ * (hipMalloc of hundreds of MB per frame is slow); this returns the pool to the driver. */
+void fiasco_amd_release_memory(void);
 
 #ifdef __cplusplus
 }

@@ -1104,3 +1104,25 @@ int fa_core_encode_frames(unsigned n, fa_job *jobs)
 }
 
 const char *fa_core_name(void) { return "oracle-cpu"; }
+
+/* staged form of the seam: the CPU oracle has nothing to make resident */
+struct oracle_staged { unsigned n; fa_job *jobs; };
+
+void *fa_core_stage(unsigned n, fa_job *jobs)
+{
+    struct oracle_staged *s = (struct oracle_staged *) malloc(sizeof *s);
+    s->n = n; s->jobs = jobs;
+    return s;
+}
+
+int fa_core_run(void *h)
+{
+    struct oracle_staged *s = (struct oracle_staged *) h;
+    unsigned i;
+    for (i = 0; i < s->n; i++)
+        if (s->jobs[i].wfa->states > s->jobs[i].wfa->basis_states)
+            fa_wfa_remove_states(s->jobs[i].wfa, s->jobs[i].wfa->basis_states);
+    return fa_core_encode_frames(s->n, s->jobs);
+}
+
+void fa_core_unstage(void *h) { free(h); }

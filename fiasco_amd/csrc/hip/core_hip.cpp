@@ -85,7 +85,7 @@ extern "C" void fiasco_amd_release_memory(void)
 
 struct Layout {
     size_t gram, diag, ipis, d5, img, imgT, norms, num, den, est, ipdo, used, tree, into, weight,
-           final_d, level_of_state, domain_type, x, y, pool_states, pix16, total;
+           final_d, level_of_state, domain_type, x, y, pool_states, pos, pix16, total;
 };
 
 static Layout make_layout(int P, int NL, int NS, int NA, int NI, int il, size_t npix)
@@ -115,6 +115,7 @@ static Layout make_layout(int P, int NL, int NS, int NA, int NI, int il, size_t 
     CARVE(x, (size_t) 2 * P * 2);
     CARVE(y, (size_t) 2 * P * 2);
     CARVE(pool_states, (size_t) (P + 8) * 2);
+    CARVE(pos, (size_t) (P + 8) * 2);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -216,6 +217,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.domain_type = (uint8_t *) (base + L.domain_type);
     F.x = (uint16_t *) (base + L.x); F.y = (uint16_t *) (base + L.y);
     F.pool_states = (int16_t *) (base + L.pool_states);
+    F.pos = (int16_t *) (base + L.pos);
 }
 
 /* allocate the slab of one frame for capacity fs.P and upload its pixel plane */

@@ -61,6 +61,7 @@ typedef struct DevFrame {
     uint8_t *level_of_state, *domain_type;
     uint16_t *x, *y;
     int16_t *pool_states;
+    int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     /* ---- results ---- */
     int      status;
     int      states, root_state;

@@ -261,7 +261,7 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
-__device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
+__device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P, states = sh.states;
     for (int lv = il + 1; lv <= level; lv++) {
@@ -326,7 +326,7 @@ __device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int l
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
-__device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
+__device__ __noinline__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 {
     const int tid = threadIdx.x, P = F.P;
     for (int s = from + tid; s < to; s += B) {
@@ -344,7 +344,7 @@ __device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 }
 
 /* codec/subdivide.c:504-541,612-644 */
-__device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
+__device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
@@ -379,7 +379,7 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 }
 
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
-__device__ void op_append(DevFrame &F, Sh &sh, int s)
+__device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
@@ -394,10 +394,50 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
     }
     __syncthreads();
     /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
-    for (int t = tid; t <= s; t += B) {
-        if (!F.domain_type[t]) continue;
-        gram_store(F, 0, s, t, gram_dot(F, s, t));
-        for (int q = 1; q < F.NL; q++) gram_store(F, q, s, t, gram_entry(F, q, s, t));
+    {
+        /* term lists (tree child weight 1 first, then the edges) of the new state s: uniform */
+        int   i1[2][MAXED + 1], n1[2], c1[2];
+        float w1[2][MAXED + 1];
+        for (int l = 0; l < 2; l++) {
+            int k = TREE(F, s, l), m = 0;
+            c1[l] = k != RANGE_;
+            if (c1[l]) { i1[l][m] = k; w1[l][m] = 1.0f; m++; }
+            for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++) { i1[l][m] = d; w1[l][m] = WEIGHT(F, s, l, e); m++; }
+            n1[l] = m;
+        }
+        for (int t = tid; t <= s; t += B) {
+            if (!F.domain_type[t]) continue;
+            /* term lists of t, loaded once and reused by every table level */
+            int   i2[2][MAXED + 1], n2[2], c2[2];
+            float w2[2][MAXED + 1];
+            for (int l = 0; l < 2; l++) {
+                int k = TREE(F, t, l), m = 0;
+                c2[l] = k != RANGE_;
+                if (c2[l]) { i2[l][m] = k; w2[l][m] = 1.0f; m++; }
+                for (int e = 0, d; (d = INTO(F, t, l, e)) != NOEDGE; e++) { i2[l][m] = d; w2[l][m] = WEIGHT(F, t, l, e); m++; }
+                n2[l] = m;
+            }
+            gram_store(F, 0, s, t, gram_dot(F, s, t));
+            for (int q = 1; q < F.NL; q++) {
+                /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
+                 * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply */
+                const float *G = GRAM(F, q - 1);
+                float ip = 0;
+                for (int l = 0; l < 2; l++)
+                    for (int a = 0; a < n1[l]; a++) {
+                        const float *row = G + (size_t) i1[l][a] * P;
+                        float sum = 0;
+                        for (int b = 0; b < n2[l]; b++) {
+                            float g = row[i2[l][b]];
+                            if (b == 0 && c2[l]) sum = g;
+                            else sum += w2[l][b] * g;
+                        }
+                        if (a == 0 && c1[l]) ip += sum;
+                        else ip += w1[l][a] * sum;
+                    }
+                gram_store(F, q, s, t, ip);
+            }
+        }
     }
     for (int a = tid; a < F.NA; a += B) {
         float ip = 0;
@@ -436,7 +476,7 @@ __device__ __forceinline__ float stage1(const Sh &sh, int d, int state, float nu
 struct Eval { float costs, m_bits, w_bits, m_err, f[MAXED]; };
 
 /* full evaluation of candidate d (codec/approx.c:495-591 without the dead :554-569) */
-__device__ void full_eval(const DevFrame &F, const Sh &sh, int d, int state, float num, float den,
+__device__ __noinline__ void full_eval(const DevFrame &F, const Sh &sh, int d, int state, float num, float den,
                           Eval &ev)
 {
     const MPState &mp = sh.mp;
@@ -450,7 +490,7 @@ __device__ void full_eval(const DevFrame &F, const Sh &sh, int d, int state, flo
         for (int j = 0; j < k; j++) ipd[k][j] = mp.sel_ipdo[k][j];
     }
     f[n] = num / den; v[n] = d; st[n] = state;
-    for (int j = 0; j < n; j++) ipd[n][j] = F.ipdo[(size_t) j * P + d];
+    for (int j = 0; j < n; j++) ipd[n][j] = F.ipdo[(size_t) j * P + state];   /* scratch is state indexed */
     for (int l = n; l >= 0; l--) {
         int mant = st[l] ? F.rpf_mant : F.dc_mant;
         float range = st[l] ? F.rpf_range : F.dc_range;
@@ -563,7 +603,7 @@ __device__ __forceinline__ float wave_min(float v)
 }
 
 /* approximate_range (codec/approx.c:74-271) at optimisation level 0 */
-__device__ void op_approx(DevFrame &F, Sh &sh)
+__device__ __noinline__ void op_approx(DevFrame &F, Sh &sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = F.P;
     SFrame &fr = sh.st[sh.sp];
@@ -591,7 +631,12 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
     }
     __syncthreads();
 
-    const int nblk = (D + 63) >> 6;
+    /* candidates are walked by STATE id (scratch, diag, Gram row, numerators are all state
+     * indexed, so every load of phase A is direct and coalesced); pos[] gives the position in
+     * the pool list that the rate model needs, -1 for states outside the pool.  State order ==
+     * position order, so the 64-state blocks keep the reference's scan order. */
+    const int S = sh.states;
+    const int nblk = (S + 63) >> 6;
     constexpr int U = 4;                 /* candidates per lane per pass: loads of all U in flight */
     unsigned long long tA = 0, tB = 0, tmark = wall_clock64();
     unsigned blockevals = 0;
@@ -607,21 +652,21 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
             for (int k = 0; k < nv; k++) { novk[k] = mp.norm_ov[k]; selk[k] = mp.sel_ipdo[nv][k]; }
             if (n) { nov_nv = mp.norm_ov[nv]; ipio_nv = mp.ipio[nv]; }
             for (int base = 0; base < nblk * 64; base += B * U) {
-                int dd[U], ss[U];
+                int dd[U], ps[U];
                 bool in[U], us[U];
                 float num[U], den[U], g[U], ip[U][MAXED - 1], e[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     dd[u] = base + u * B + tid;
-                    in[u] = dd[u] < D;
-                    ss[u] = in[u] ? F.pool_states[dd[u]] : 0;
+                    ps[u] = dd[u] < S ? (int) F.pos[dd[u]] : -1;
+                    in[u] = ps[u] >= 0;
                     us[u] = (in[u] && n) ? F.used[dd[u]] != 0 : !in[u];
                 }
                 if (n == 0) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        den[u] = in[u] ? diag[ss[u]] : 1.0f;
-                        num[u] = in[u] ? numrow[ss[u]] : 0.0f;
+                        den[u] = in[u] ? diag[dd[u]] : 1.0f;
+                        num[u] = in[u] ? numrow[dd[u]] : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < U; u++) {
@@ -637,7 +682,7 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
                         bool on = !us[u];
                         num[u] = on ? F.num[dd[u]] : 0.0f;
                         den[u] = on ? F.den[dd[u]] : 1.0f;
-                        g[u] = on ? Grow[ss[u]] : 0.0f;
+                        g[u] = on ? Grow[dd[u]] : 0.0f;
 #pragma unroll
                         for (int k = 0; k < MAXED - 1; k++)
                             ip[u][k] = (on && k < nv) ? F.ipdo[(size_t) k * P + dd[u]] : 0.0f;
@@ -659,10 +704,8 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     e[u] = BIGF;
-                    if (in[u]) {
-                        if (!us[u]) e[u] = stage1(sh, dd[u], ss[u], num[u], den[u]);
-                        F.est[dd[u]] = e[u];
-                    }
+                    if (in[u] && !us[u]) e[u] = stage1(sh, ps[u], dd[u], num[u], den[u]);
+                    if (dd[u] < S) F.est[dd[u]] = e[u];
                     float bm = wave_min(e[u]);
                     int blk = ((base + u * B) >> 6) + wave;
                     if (lane == 0 && blk < NBLOCKMIN) sh.blockmin[blk] = bm;
@@ -687,12 +730,12 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
                     int jb = __ffsll((long long) mask) - 1;
                     lastb = jb;
                     int d = ((bb + jb) << 6) + lane;
-                    float e = (d < D) ? F.est[d] : BIGF;
+                    float e = (d < S) ? F.est[d] : BIGF;
                     bool pass = e < m;
                     Eval ev;
                     ev.costs = BIGF; ev.m_bits = ev.w_bits = ev.m_err = 0;
                     for (int k = 0; k < MAXED; k++) ev.f[k] = 0;
-                    if (pass) full_eval(F, sh, d, F.pool_states[d], F.num[d], F.den[d], ev);
+                    if (pass) full_eval(F, sh, F.pos[d], d, F.num[d], F.den[d], ev);
                     evals += (unsigned) __popcll(__ballot(pass));
                     blockevals++;
                     int last = -1, win = -1;
@@ -714,7 +757,8 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
             }
             if (lane == 0) {
                 F.n_fulleval += evals;
-                int index = b_index;
+                const int bstate = b_index;                       /* winning STATE of the step */
+                int index = bstate >= 0 ? (int) F.pos[bstate] : -1;   /* its pool position */
                 if (index >= 0) {
                     if (b_cost < mp.costs) {
                         mp.costs = b_cost; mp.err = b_err;
@@ -723,11 +767,11 @@ __device__ void op_approx(DevFrame &F, Sh &sh)
                         mp.best_n = n + 1;
                     }
                     mp.indices[n] = (short) index;
-                    mp.into[n] = F.pool_states[index];
-                    F.used[index] = 1;
-                    mp.norm_ov[n] = F.den[index];
-                    mp.ipio[n] = F.num[index];
-                    for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + index];
+                    mp.into[n] = (short) bstate;
+                    F.used[bstate] = 1;
+                    mp.norm_ov[n] = F.den[bstate];
+                    mp.ipio[n] = F.num[bstate];
+                    for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + bstate];
                     mp.row_state = mp.into[n];
                     mp.n = n + 1;
                     if (mp.n < F.max_elements) mp_step_prepare(F, sh);
@@ -798,7 +842,17 @@ __device__ void tree_update_dev(Sh &sh, int ML, int child, int level, int which)
 /* model snapshots: short runs of 128-bit LDS copies (lane 0) */
 __device__ __forceinline__ void copy16(uint4 *dst, const uint4 *src, int n)
 {
-    for (int i = 0; i < n; i++) dst[i] = src[i];
+    /* 8 independent 128-bit LDS reads in flight, then 8 writes: a dependent read->write
+     * chain per element would cost one LDS latency (~64 cycles) each */
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = src[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[i + k] = t[k];
+    }
+    for (; i < n; i++) dst[i] = src[i];
 }
 
 __device__ void snap_save(const DevFrame &F, Sh &sh, int depth, int which)
@@ -839,7 +893,11 @@ __device__ float final_distribution_dev(const DevFrame &F, int s)
 __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
 {
     const int s = sh.states;
-    if (!aux && sh.pool.n < sh.pool.max_domains) F.pool_states[sh.pool.n++] = (short) s;
+    F.pos[s] = -1;
+    if (!aux && sh.pool.n < sh.pool.max_domains) {
+        F.pos[s] = (short) sh.pool.n;
+        F.pool_states[sh.pool.n++] = (short) s;
+    }
     fr.rrange.into[0] = NOEDGE;
     fr.rrange.tree = s;
     for (int l = 0; l < 2; l++) {
@@ -865,7 +923,7 @@ __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
 }
 
 /* advance the partition search until a data-parallel operation is required */
-__device__ void serial_advance(DevFrame &F, Sh &sh)
+__device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
 {
     const int ML = F.ML;
     for (;;) {
@@ -1034,7 +1092,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
 }
 
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
-__device__ void basis_init(DevFrame &F, Sh &sh)
+__device__ __noinline__ void basis_init(DevFrame &F, Sh &sh)
 {
     const int nb = F.basis_states, il = F.images_level;
     for (int s = 0; s < nb; s++) {
@@ -1102,11 +1160,14 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         for (int i = 0; i <= MAXED; i++) { m.count[i] = 1; m.total++; }
         m.n = 0; m.max_domains = (unsigned short) F.pool_max; m.y_index = 0;
         m.d0_index = 0; m.d0_yindex = 0; m.d0_n = 0;
-        for (int s = 0; s < F.basis_states; s++)
+        for (int s = 0; s < F.basis_states; s++) {
+            F.pos[s] = -1;
             if ((F.domain_type[s] & 2) && m.n < m.max_domains) {
+                F.pos[s] = (short) m.n;
                 F.pool_states[m.n++] = (short) s;
                 if (s == 0) m.d0_n = 1;
             }
+        }
         /* aac model, all-ones (coeff.c:297-310) */
         sh.n16 = (64 + 2 * F.coeff_size + 15) / 16;
         if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16) sh.failed = FC_ERR_INTERNAL;

@@ -51,7 +51,8 @@ class Stats(ctypes.Structure):
                 ("t_approx", ctypes.c_ulonglong), ("t_ipis", ctypes.c_ulonglong),
                 ("t_append", ctypes.c_ulonglong), ("t_serial", ctypes.c_ulonglong),
                 ("t_total", ctypes.c_ulonglong), ("t_mpA", ctypes.c_ulonglong),
-                ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong)]
+                ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong),
+                ("dbg", ctypes.c_ulonglong * 8)]
 
 
 def build(verbose=False):

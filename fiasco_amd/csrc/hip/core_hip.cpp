@@ -371,6 +371,7 @@ static int collect(Staged *S, FrameSlot &fs)
     g_stats.t_init += F.t_init; g_stats.t_approx += F.t_approx; g_stats.t_ipis += F.t_ipis;
     g_stats.t_append += F.t_append; g_stats.t_serial += F.t_serial; g_stats.t_total += F.t_total;
     g_stats.t_mpA += F.t_mpA; g_stats.t_mpB += F.t_mpB; g_stats.n_blockevals += F.n_blockevals;
+    for (int k = 0; k < 8; k++) g_stats.dbg[k] += F.dbg[k];
     return 1;
 }
 

@@ -72,6 +72,7 @@ typedef struct DevFrame {
     /* ---- time per phase in 100 MHz wall-clock ticks (lane 0) ---- */
     unsigned long long t_init, t_approx, t_ipis, t_append, t_serial, t_total;
     unsigned long long t_mpA, t_mpB, n_blockevals;
+    unsigned long long dbg[8];          /* free-form developer counters (shader clock ticks) */
     /* ---- optional per-call trace (FIASCO_AMD_TRACE), compared with the oracle's ---- */
     struct FcTrace *trace;
     int      trace_cap, trace_n;

@@ -108,6 +108,10 @@ struct Sh {
     MPState  mp;
     float    blockmin[NBLOCKMIN];
     float    pixels[1024];
+    unsigned long long tk[5];      /* ticks per op (lane 0) */
+    /* term lists of the state being appended (uniform for the whole workgroup) */
+    int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2];
+    float    gs_w[2][MAXED + 1];
     int      states;               /* wfa->states */
     int      failed;
 };
@@ -261,7 +265,7 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
-__device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
+__device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P, states = sh.states;
     for (int lv = il + 1; lv <= level; lv++) {
@@ -295,10 +299,11 @@ __device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int a
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
-            for (int j0 = 0; j0 < cnt; j0 += 4) {
-                float v[4][2][MAXED + 1];
+            constexpr int JG = 2;          /* slots per group: 2 x 12 gathers in flight per lane */
+            for (int j0 = 0; j0 < cnt; j0 += JG) {
+                float v[JG][2][MAXED + 1];
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++)
+                for (int jj = 0; jj < JG; jj++)
 #pragma unroll
                     for (int l = 0; l < 2; l++)
 #pragma unroll
@@ -307,7 +312,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int a
                             v[jj][l][i] = on ? src0[(size_t) ((j0 + jj) * 2 + l) * P + idx[l][i]] : 0.0f;
                         }
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
+                for (int jj = 0; jj < JG; jj++) {
                     if (j0 + jj >= cnt) break;
                     float acc = 0;
 #pragma unroll
@@ -326,7 +331,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int a
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
-__device__ __noinline__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
+__device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 {
     const int tid = threadIdx.x, P = F.P;
     for (int s = from + tid; s < to; s += B) {
@@ -344,7 +349,7 @@ __device__ __noinline__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 }
 
 /* codec/subdivide.c:504-541,612-644 */
-__device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
+__device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
@@ -379,7 +384,7 @@ __device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 }
 
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
-__device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
+__device__ void op_append(DevFrame &F, Sh &sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
@@ -396,26 +401,36 @@ __device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
     /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
     {
         /* term lists (tree child weight 1 first, then the edges) of the new state s: uniform */
-        int   i1[2][MAXED + 1], n1[2], c1[2];
-        float w1[2][MAXED + 1];
-        for (int l = 0; l < 2; l++) {
-            int k = TREE(F, s, l), m = 0;
-            c1[l] = k != RANGE_;
-            if (c1[l]) { i1[l][m] = k; w1[l][m] = 1.0f; m++; }
-            for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++) { i1[l][m] = d; w1[l][m] = WEIGHT(F, s, l, e); m++; }
-            n1[l] = m;
+        if (tid < 2) {          /* lists of s into LDS: slot 0 = tree child (if any), then edges */
+            int l = tid, k = TREE(F, s, l), m = 0;
+            sh.gs_c[l] = k != RANGE_;
+            if (k != RANGE_) { sh.gs_idx[l][m] = k; sh.gs_w[l][m] = 1.0f; m++; }
+            for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++) { sh.gs_idx[l][m] = d; sh.gs_w[l][m] = WEIGHT(F, s, l, e); m++; }
+            sh.gs_n[l] = m;
         }
+        __syncthreads();
         for (int t = tid; t <= s; t += B) {
             if (!F.domain_type[t]) continue;
-            /* term lists of t, loaded once and reused by every table level */
-            int   i2[2][MAXED + 1], n2[2], c2[2];
+            /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
+             * once and reused by every table level */
+            int   i2[2][MAXED + 1];
             float w2[2][MAXED + 1];
+            unsigned m2[2];
+#pragma unroll
             for (int l = 0; l < 2; l++) {
-                int k = TREE(F, t, l), m = 0;
-                c2[l] = k != RANGE_;
-                if (c2[l]) { i2[l][m] = k; w2[l][m] = 1.0f; m++; }
-                for (int e = 0, d; (d = INTO(F, t, l, e)) != NOEDGE; e++) { i2[l][m] = d; w2[l][m] = WEIGHT(F, t, l, e); m++; }
-                n2[l] = m;
+                int k = TREE(F, t, l);
+                m2[l] = k != RANGE_ ? 1u : 0u;
+                i2[l][0] = k != RANGE_ ? k : 0;
+                w2[l][0] = 1.0f;
+                bool live = true;
+#pragma unroll
+                for (int e = 0; e < MAXED; e++) {
+                    int d = live ? INTO(F, t, l, e) : NOEDGE;
+                    live = live && d != NOEDGE;
+                    i2[l][e + 1] = live ? d : 0;
+                    w2[l][e + 1] = live ? WEIGHT(F, t, l, e) : 0.0f;
+                    m2[l] |= live ? (2u << e) : 0u;
+                }
             }
             gram_store(F, 0, s, t, gram_dot(F, s, t));
             for (int q = 1; q < F.NL; q++) {
@@ -423,18 +438,24 @@ __device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
                  * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply */
                 const float *G = GRAM(F, q - 1);
                 float ip = 0;
-                for (int l = 0; l < 2; l++)
-                    for (int a = 0; a < n1[l]; a++) {
-                        const float *row = G + (size_t) i1[l][a] * P;
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                    const int na = sh.gs_n[l], ca = sh.gs_c[l];
+                    for (int a = 0; a < na; a++) {
+                        const float *row = G + (size_t) sh.gs_idx[l][a] * P;
+                        float g[MAXED + 1];
+#pragma unroll
+                        for (int b = 0; b <= MAXED; b++)
+                            g[b] = ((m2[l] >> b) & 1u) ? row[i2[l][b]] : 0.0f;
                         float sum = 0;
-                        for (int b = 0; b < n2[l]; b++) {
-                            float g = row[i2[l][b]];
-                            if (b == 0 && c2[l]) sum = g;
-                            else sum += w2[l][b] * g;
-                        }
-                        if (a == 0 && c1[l]) ip += sum;
-                        else ip += w1[l][a] * sum;
+                        if (m2[l] & 1u) sum = g[0];
+#pragma unroll
+                        for (int b = 1; b <= MAXED; b++)
+                            if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[b];
+                        if (a == 0 && ca) ip += sum;
+                        else ip += sh.gs_w[l][a] * sum;
                     }
+                }
                 gram_store(F, q, s, t, ip);
             }
         }
@@ -455,373 +476,7 @@ __device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
     }
 }
 
-/* ---- matching pursuit ---------------------------------------------------------- */
-
-/* stage-1 estimate of candidate position d (codec/approx.c:433-462) */
-__device__ __forceinline__ float stage1(const Sh &sh, int d, int state, float num, float den)
-{
-    const MPState &mp = sh.mp;
-    short merged[MAXED + 1];
-    int nn = 0, placed = 0;
-    for (int i = 0; i < mp.np; i++) {
-        if (!placed && d < mp.psorted[i]) { merged[nn++] = (short) d; placed = 1; }
-        merged[nn++] = mp.psorted[i];
-    }
-    if (!placed) merged[nn++] = (short) d;
-    float matrix_bits = pool_bits_sorted(merged, nn, sh);
-    float weights_bits = state ? mp.wb_nd : mp.wb_dc;
-    return (matrix_bits + weights_bits + mp.ab) * mp.price + mp.err - num * num / den;
-}
-
-struct Eval { float costs, m_bits, w_bits, m_err, f[MAXED]; };
-
-/* full evaluation of candidate d (codec/approx.c:495-591 without the dead :554-569) */
-__device__ __noinline__ void full_eval(const DevFrame &F, const Sh &sh, int d, int state, float num, float den,
-                          Eval &ev)
-{
-    const MPState &mp = sh.mp;
-    const int n = mp.n, P = F.P;
-    float f[MAXED], r[MAXED], ipd[MAXED][MAXED], nov[MAXED + 1], ipio[MAXED + 1];
-    int   v[MAXED], st[MAXED];
-    for (int k = 0; k < n; k++) {
-        nov[k] = mp.norm_ov[k]; ipio[k] = mp.ipio[k];
-        f[k] = ipio[k] / nov[k];
-        v[k] = mp.indices[k]; st[k] = mp.into[k];
-        for (int j = 0; j < k; j++) ipd[k][j] = mp.sel_ipdo[k][j];
-    }
-    f[n] = num / den; v[n] = d; st[n] = state;
-    for (int j = 0; j < n; j++) ipd[n][j] = F.ipdo[(size_t) j * P + state];   /* scratch is state indexed */
-    for (int l = n; l >= 0; l--) {
-        int mant = st[l] ? F.rpf_mant : F.dc_mant;
-        float range = st[l] ? F.rpf_range : F.dc_range;
-        r[l] = f[l] = btor_dev(rtob_dev(f[l], mant, range), mant, range);
-        for (int k = 0; k < l; k++) f[k] -= f[l] * ipd[l][k] / nov[k];
-    }
-    {   /* rate of the rounded combination */
-        short sorted[MAXED + 1];
-        int nn = 0;
-        float wb = 0;
-        for (int k = 0; k <= n; k++)
-            if (f[k] != 0) {
-                if (st[k]) wb = (float) ((double) wb - sh.lglv[rtob_dev(f[k], F.rpf_mant, F.rpf_range)]);
-                else       wb = (float) ((double) wb - sh.lgdc[rtob_dev(f[k], F.dc_mant, F.dc_range)]);
-                int j = nn++;
-                while (j > 0 && sorted[j - 1] > v[k]) { sorted[j] = sorted[j - 1]; j--; }
-                sorted[j] = (short) v[k];
-            }
-        ev.w_bits = wb;
-        ev.m_bits = pool_bits_sorted(sorted, nn, sh);
-    }
-    nov[n] = den; ipio[n] = num;
-    for (int k = 0; k <= n; k++)
-        for (int l = k + 1; l <= n; l++) r[k] += ipd[l][k] * r[l] / nov[k];
-    float m_err = mp.norm;
-    for (int k = 0; k <= n; k++) m_err += r[k] * r[k] * nov[k] - 2 * r[k] * ipio[k];
-    ev.m_err = m_err;
-    ev.costs = (ev.m_bits + ev.w_bits + mp.ab) * mp.price + m_err;
-    for (int k = 0; k <= n; k++) ev.f[k] = f[k];
-}
-
-/* log2 tables of the two coefficient contexts and of the edge-count model */
-__device__ void mp_tables(const DevFrame &F, Sh &sh, int level)
-{
-    const int tid = threadIdx.x;
-    if (tid < F.dcs)
-        sh.lgdc[tid] = log2((double) (sh.cb.cnt[tid] / (float) sh.cb.tot[0]));
-    else if (tid >= 64 && tid < 64 + F.sy) {
-        int sym = tid - 64, ctx = level - F.lc_min;
-        sh.lglv[sym] = log2((double) (sh.cb.cnt[F.dcs + ctx * F.sy + sym] / (float) sh.cb.tot[ctx + 1]));
-    } else if (tid >= 128 && tid < 128 + MAXED + 1)
-        sh.Ltab[tid - 128] = (float) -log2((double) (sh.pool.count[tid - 128] / (float) sh.pool.total));
-    else if (tid == 192) {
-        /* nested domain-0 model, gray: y_state < 0 (domain-pool.c:367-402,773-782) */
-        float q0 = 0, q1 = 0;
-        if (sh.pool.d0_n) {
-            float m0 = sh.m0tab[qac_shift(sh.pool.d0_index)];
-            float m1 = (float) qac_shift(sh.pool.d0_index);
-            q0 += m0;
-            q1 += m0; q1 -= m0; q1 += m1;
-        }
-        sh.Q0 = q0; sh.Q1 = q1;
-    }
-}
-
-/* serial part of a step start: sorted list of kept vectors, the two stage-1 weight prices */
-__device__ void mp_step_prepare(const DevFrame &F, Sh &sh)
-{
-    MPState &mp = sh.mp;
-    float wb = 0;
-    int np = 0;
-    for (int k = 0; k < mp.n; k++)
-        if (mp.weight[k] != 0) {
-            if (mp.into[k]) wb = (float) ((double) wb - sh.lglv[rtob_dev(mp.weight[k], F.rpf_mant, F.rpf_range)]);
-            else            wb = (float) ((double) wb - sh.lgdc[rtob_dev(mp.weight[k], F.dc_mant, F.dc_range)]);
-            int j = np++;
-            while (j > 0 && mp.psorted[j - 1] > mp.indices[k]) { mp.psorted[j] = mp.psorted[j - 1]; j--; }
-            mp.psorted[j] = mp.indices[k];
-        }
-    mp.np = np;
-    mp.wb_nd = (float) ((double) wb - sh.lglv[rtob_dev(0.5f, F.rpf_mant, F.rpf_range)]);
-    mp.wb_dc = (float) ((double) wb - sh.lgdc[rtob_dev(0.5f, F.dc_mant, F.dc_range)]);
-    mp.min_costs = mp.costs;            /* full_search is off in this build */
-    mp.b_index = -1;
-}
-
-/* rle_update + aac_update on acceptance (domain-pool.c:795-830, coeff.c:242-267) */
-__device__ void models_update(const DevFrame &F, Sh &sh, const short *indices, const short *into,
-                              const float *weight, int level)
-{
-    Pool &m = sh.pool;
-    int state_0 = 0, edge = 0;
-    for (; indices[edge] != NOEDGE; edge++)
-        if (into[edge] == 0) state_0 = 1;
-    m.count[edge]++;
-    m.total++;
-    if (m.d0_n) {
-        m.d0_index++;
-        if (state_0) { m.d0_index--; m.d0_index >>= 1; }
-        if (m.d0_index > 1020) m.d0_index = 1020;
-    }
-    m.y_index++;                                   /* gray: the y state is never used */
-    if (m.y_index > 1020) m.y_index = 1020;
-    int ctx = level - F.lc_min;
-    for (int e = 0; into[e] != NOEDGE; e++)
-        if (into[e]) {
-            sh.cb.cnt[F.dcs + ctx * F.sy + rtob_dev(weight[e], F.rpf_mant, F.rpf_range)]++;
-            sh.cb.tot[ctx + 1]++;
-        } else {
-            sh.cb.cnt[rtob_dev(weight[e], F.dc_mant, F.dc_range)]++;
-            sh.cb.tot[0]++;
-        }
-}
-
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-
-/* approximate_range (codec/approx.c:74-271) at optimisation level 0 */
-__device__ __noinline__ void op_approx(DevFrame &F, Sh &sh)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = F.P;
-    SFrame &fr = sh.st[sh.sp];
-    MPState &mp = sh.mp;
-    const int level = fr.lrange.level;
-    const float size = (float) (1u << level);
-    const int q = level - F.images_level;          /* Gram table index of this level */
-    const int D = sh.pool.n;
-
-    mp_tables(F, sh, level);
-    __syncthreads();
-    if (tid == 0) {
-        mp.n = 0; mp.best_n = 0;
-        mp.D = D; mp.N = D;
-        mp.level = level; mp.image = fr.lrange.image; mp.address = fr.lrange.address;
-        mp.norm = F.norms[mp.image];
-        mp.ab = fr.lrange.tree_bits;
-        mp.price = fr.price;
-        mp.err = mp.norm;
-        mp.weights_bits = 0;
-        mp.matrix_bits = pool_bits_sorted(nullptr, 0, sh);
-        mp.costs = (mp.matrix_bits + mp.weights_bits + mp.ab) * mp.price + mp.err;
-        mp.index = -1;
-        mp_step_prepare(F, sh);
-    }
-    __syncthreads();
-
-    /* candidates are walked by STATE id (scratch, diag, Gram row, numerators are all state
-     * indexed, so every load of phase A is direct and coalesced); pos[] gives the position in
-     * the pool list that the rate model needs, -1 for states outside the pool.  State order ==
-     * position order, so the 64-state blocks keep the reference's scan order. */
-    const int S = sh.states;
-    const int nblk = (S + 63) >> 6;
-    constexpr int U = 4;                 /* candidates per lane per pass: loads of all U in flight */
-    unsigned long long tA = 0, tB = 0, tmark = wall_clock64();
-    unsigned blockevals = 0;
-    for (;;) {
-        const int n = mp.n;
-        /* ---------------- phase A: Gram-Schmidt update + stage-1 estimate ---------------- */
-        {
-            const float *Grow = n ? GRAM(F, q) + (size_t) mp.row_state * P : nullptr;
-            const float *diag = F.diag + (size_t) q * P;
-            const float *numrow = F.ipis + (size_t) mp.image * P;
-            const int nv = n - 1;
-            float novk[MAXED], selk[MAXED], nov_nv = 1, ipio_nv = 0;
-            for (int k = 0; k < nv; k++) { novk[k] = mp.norm_ov[k]; selk[k] = mp.sel_ipdo[nv][k]; }
-            if (n) { nov_nv = mp.norm_ov[nv]; ipio_nv = mp.ipio[nv]; }
-            for (int base = 0; base < nblk * 64; base += B * U) {
-                int dd[U], ps[U];
-                bool in[U], us[U];
-                float num[U], den[U], g[U], ip[U][MAXED - 1], e[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    dd[u] = base + u * B + tid;
-                    ps[u] = dd[u] < S ? (int) F.pos[dd[u]] : -1;
-                    in[u] = ps[u] >= 0;
-                    us[u] = (in[u] && n) ? F.used[dd[u]] != 0 : !in[u];
-                }
-                if (n == 0) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        den[u] = in[u] ? diag[dd[u]] : 1.0f;
-                        num[u] = in[u] ? numrow[dd[u]] : 0.0f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (!in[u]) continue;
-                        bool uu = den[u] / size < MIN_NORM;
-                        if (!uu) uu = fabsf(num[u]) < MIN_NORM;
-                        us[u] = uu;
-                        F.num[dd[u]] = num[u]; F.den[dd[u]] = den[u]; F.used[dd[u]] = uu;
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        bool on = !us[u];
-                        num[u] = on ? F.num[dd[u]] : 0.0f;
-                        den[u] = on ? F.den[dd[u]] : 1.0f;
-                        g[u] = on ? Grow[dd[u]] : 0.0f;
-#pragma unroll
-                        for (int k = 0; k < MAXED - 1; k++)
-                            ip[u][k] = (on && k < nv) ? F.ipdo[(size_t) k * P + dd[u]] : 0.0f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (us[u]) continue;
-                        float t = g[u];
-#pragma unroll
-                        for (int k = 0; k < MAXED - 1; k++)
-                            if (k < nv) t -= ip[u][k] / novk[k] * selk[k];
-                        F.ipdo[(size_t) nv * P + dd[u]] = t;
-                        den[u] -= t * t / nov_nv;
-                        num[u] -= ipio_nv / nov_nv * t;
-                        if (den[u] / size < MIN_NORM) { us[u] = true; F.used[dd[u]] = 1; }
-                        F.num[dd[u]] = num[u]; F.den[dd[u]] = den[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    e[u] = BIGF;
-                    if (in[u] && !us[u]) e[u] = stage1(sh, ps[u], dd[u], num[u], den[u]);
-                    if (dd[u] < S) F.est[dd[u]] = e[u];
-                    float bm = wave_min(e[u]);
-                    int blk = ((base + u * B) >> 6) + wave;
-                    if (lane == 0 && blk < NBLOCKMIN) sh.blockmin[blk] = bm;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { unsigned long long t = wall_clock64(); tA += t - tmark; tmark = t; }
-        /* ------- phase B: ordered replay + commit of the step, all inside wave 0 ------- */
-        if (wave == 0) {
-            float m = mp.min_costs;
-            unsigned evals = 0;
-            /* lane 0 keeps the best candidate of the step in registers */
-            int b_index = -1;
-            float b_cost = 0, b_mbits = 0, b_wbits = 0, b_err = 0, b_f[MAXED];
-            for (int bb = 0; bb < nblk; bb += 64) {
-                float bm = (bb + lane < nblk) ? sh.blockmin[bb + lane] : BIGF;
-                int lastb = -1;
-                for (;;) {
-                    unsigned long long mask = __ballot(bm < m && lane > lastb);
-                    if (!mask) break;
-                    int jb = __ffsll((long long) mask) - 1;
-                    lastb = jb;
-                    int d = ((bb + jb) << 6) + lane;
-                    float e = (d < S) ? F.est[d] : BIGF;
-                    bool pass = e < m;
-                    Eval ev;
-                    ev.costs = BIGF; ev.m_bits = ev.w_bits = ev.m_err = 0;
-                    for (int k = 0; k < MAXED; k++) ev.f[k] = 0;
-                    if (pass) full_eval(F, sh, F.pos[d], d, F.num[d], F.den[d], ev);
-                    evals += (unsigned) __popcll(__ballot(pass));
-                    blockevals++;
-                    int last = -1, win = -1;
-                    for (;;) {
-                        unsigned long long ok = __ballot(pass && lane > last && e < m && ev.costs < m);
-                        if (!ok) break;
-                        int j = __ffsll((long long) ok) - 1;
-                        last = j; win = j;
-                        m = __shfl(ev.costs, j);
-                    }
-                    if (win >= 0) {                 /* wave-uniform */
-                        b_index = ((bb + jb) << 6) + win;
-                        b_cost = __shfl(ev.costs, win); b_mbits = __shfl(ev.m_bits, win);
-                        b_wbits = __shfl(ev.w_bits, win); b_err = __shfl(ev.m_err, win);
-#pragma unroll
-                        for (int k = 0; k < MAXED; k++) b_f[k] = __shfl(ev.f[k], win);
-                    }
-                }
-            }
-            if (lane == 0) {
-                F.n_fulleval += evals;
-                const int bstate = b_index;                       /* winning STATE of the step */
-                int index = bstate >= 0 ? (int) F.pos[bstate] : -1;   /* its pool position */
-                if (index >= 0) {
-                    if (b_cost < mp.costs) {
-                        mp.costs = b_cost; mp.err = b_err;
-                        mp.matrix_bits = b_mbits; mp.weights_bits = b_wbits;
-                        for (int k = 0; k <= n; k++) mp.weight[k] = b_f[k];
-                        mp.best_n = n + 1;
-                    }
-                    mp.indices[n] = (short) index;
-                    mp.into[n] = (short) bstate;
-                    F.used[bstate] = 1;
-                    mp.norm_ov[n] = F.den[bstate];
-                    mp.ipio[n] = F.num[bstate];
-                    for (int k = 0; k < n; k++) mp.sel_ipdo[n][k] = F.ipdo[(size_t) k * P + bstate];
-                    mp.row_state = mp.into[n];
-                    mp.n = n + 1;
-                    if (mp.n < F.max_elements) mp_step_prepare(F, sh);
-                }
-                mp.index = index;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { unsigned long long t = wall_clock64(); tB += t - tmark; tmark = t; }
-        if (!(mp.n < F.max_elements && mp.index >= 0)) break;
-    }
-    if (tid == 0) { F.t_mpA += tA; F.t_mpB += tB; F.n_blockevals += blockevals; }
-
-    if (tid == 0) {
-        Range &lr = fr.lrange;
-        mp.indices[mp.best_n] = NOEDGE;
-        float costs = (mp.matrix_bits + mp.weights_bits + mp.ab) * mp.price + mp.err;
-        if (costs < fr.max_costs) {
-            int ni = 0;
-            for (int oi = 0; mp.indices[oi] != NOEDGE; oi++)
-                if (mp.weight[oi] != 0) {
-                    mp.indices[ni] = mp.indices[oi]; mp.into[ni] = mp.into[oi];
-                    mp.weight[ni] = mp.weight[oi];
-                    ni++;
-                }
-            mp.indices[ni] = NOEDGE; mp.into[ni] = NOEDGE;
-            models_update(F, sh, mp.indices, mp.into, mp.weight, level);
-            int e = 0;
-            for (; mp.indices[e] != NOEDGE; e++) { lr.into[e] = mp.into[e]; lr.weight[e] = mp.weight[e]; }
-            lr.into[e] = NOEDGE;
-            lr.matrix_bits = mp.matrix_bits; lr.weights_bits = mp.weights_bits; lr.err = mp.err;
-        } else {
-            lr.into[0] = NOEDGE;
-            costs = MAXCOSTS;
-        }
-        fr.lincomb = costs;
-        if (F.trace && F.trace_n < F.trace_cap) {
-            FcTrace &t = F.trace[F.trace_n];
-            t.seq = F.trace_n; t.level = level; t.image = mp.image; t.D = D; t.states = sh.states;
-            t.cost = costs; t.err = mp.err; t.mbits = mp.matrix_bits; t.wbits = mp.weights_bits;
-            int e = 0;
-            for (; e < 6; e++) { t.into[e] = -1; if (e < 5) t.w[e] = 0; }
-            for (e = 0; costs < MAXCOSTS && lr.into[e] != NOEDGE; e++) { t.into[e] = lr.into[e]; t.w[e] = lr.weight[e]; }
-            t.nedges = e;
-            F.trace_n++;
-        }
-        F.bytes_mp += 4ull * D * (2 + mp.n) + 4ull * (1u << level);
-        F.n_mp++; F.n_steps += mp.n;
-    }
-}
+#include "mp_device.inc"
 
 /* ------------------------------------------------------------------ serial state machine */
 
@@ -846,11 +501,11 @@ __device__ __forceinline__ void copy16(uint4 *dst, const uint4 *src, int n)
      * chain per element would cost one LDS latency (~64 cycles) each */
     int i = 0;
     for (; i + 8 <= n; i += 8) {
-        uint4 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = src[i + k];
-#pragma unroll
-        for (int k = 0; k < 8; k++) dst[i + k] = t[k];
+        /* named temporaries: an indexed local array ends up in scratch memory */
+        uint4 t0 = src[i], t1 = src[i + 1], t2 = src[i + 2], t3 = src[i + 3];
+        uint4 t4 = src[i + 4], t5 = src[i + 5], t6 = src[i + 6], t7 = src[i + 7];
+        dst[i] = t0; dst[i + 1] = t1; dst[i + 2] = t2; dst[i + 3] = t3;
+        dst[i + 4] = t4; dst[i + 5] = t5; dst[i + 6] = t6; dst[i + 7] = t7;
     }
     for (; i < n; i++) dst[i] = src[i];
 }
@@ -923,7 +578,7 @@ __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
 }
 
 /* advance the partition search until a data-parallel operation is required */
-__device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
+__device__ void serial_advance(DevFrame &F, Sh &sh)
 {
     const int ML = F.ML;
     for (;;) {
@@ -1092,7 +747,7 @@ __device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
 }
 
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
-__device__ __noinline__ void basis_init(DevFrame &F, Sh &sh)
+__device__ void basis_init(DevFrame &F, Sh &sh)
 {
     const int nb = F.basis_states, il = F.images_level;
     for (int s = 0; s < nb; s++) {
@@ -1133,6 +788,7 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         F.n_mp = F.n_steps = F.n_blocks = F.n_appends = F.n_fulleval = 0;
         F.trace_n = 0;
         F.t_mpA = F.t_mpB = F.n_blockevals = 0;
+        for (int k = 0; k < 8; k++) F.dbg[k] = 0;
         /* rows of the basis states (input/basis.c:61-114, input/read.c:219-340) */
         for (int s = 0; s < F.basis_states; s++) {
             F.final_d[s] = F.b_final[s];
@@ -1188,7 +844,10 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         sh.sp = 0;
         serial_advance(F, sh);
     }
-    unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_begin = wall_clock64();
+    /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
+    unsigned long long *tk = sh.tk;
+    if (tid == 0) for (int k = 0; k < 5; k++) tk[k] = 0;
+    unsigned long long t_begin = wall_clock64();
     for (;;) {
         __syncthreads();
         const int op = sh.op;

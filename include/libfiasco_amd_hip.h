@@ -29,6 +29,7 @@ typedef struct fiasco_amd_stats {
     /* inside matching pursuit: candidate-parallel phase, ordered-replay phase (ticks); number
      * of 64-candidate blocks whose survivors were fully evaluated */
     unsigned long long t_mpA, t_mpB, n_blockevals;
+    unsigned long long dbg[8];      /* free-form developer counters */
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

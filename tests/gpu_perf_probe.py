@@ -43,6 +43,8 @@ for r in range(reps):
              st.n_mp // max(ok, 1), st.n_steps // max(ok, 1), st.n_fulleval // max(ok, 1)))
     print("  mp: phaseA %.1f%% phaseB %.1f%% of frame; block evals/call %.2f, full evals/call %.1f"
           % (100.0 * st.t_mpA / tt, 100.0 * st.t_mpB / tt, st.n_blockevals / max(st.n_mp, 1), st.n_fulleval / max(st.n_mp, 1)))
+    if any(st.dbg):
+        print("  dbg:", " ".join("%.3g" % (x / max(ok, 1)) for x in st.dbg))
     if not ok:
         print(lib.error_message())
 print("  md5 frame0:", hashlib.md5(out[0]).hexdigest() if out[0] else None, "sizes", sorted(set(len(o) for o in out if o))[:4])

@@ -91,7 +91,16 @@ struct __attribute__((aligned(16))) CoeffBuf {
 #define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
 #define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
 
+struct RoundBox {                    /* mp_reg.inc: winner of the running step, in LDS */
+    float m;                         /* running min_costs */
+    int   state;                     /* winning state or -1 */
+    float cost, mbits, wbits, err, f[MAXED];
+    float num, den, ip[MAXED - 1];
+    unsigned evals, blockevals;
+};
+
 struct Sh {
+    RoundBox rb;
     SFrame   st[FC_MAXDEPTH];
     int      sp;
     int      op, a0, a1, a2, a3;
@@ -789,6 +798,24 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         F.trace_n = 0;
         F.t_mpA = F.t_mpB = F.n_blockevals = 0;
         for (int k = 0; k < 8; k++) F.dbg[k] = 0;
+#ifdef FC_LATENCY_PROBE
+        {   /* developer probe: dependent-load latency on a small global array (L2 resident)
+             * and on a freshly stored one */
+            volatile float *a = F.est;
+            for (int k = 0; k < 64; k++) a[k] = (float) ((k * 7 + 3) & 63);
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned long long c0 = __builtin_readcyclecounter();
+            int idx = 0;
+            for (int k = 0; k < 64; k++) idx = (int) a[idx];
+            unsigned long long c1 = __builtin_readcyclecounter();
+            F.dbg[5] = (c1 - c0) / 64 + (idx & 0);
+            /* store -> load of the same word */
+            c0 = __builtin_readcyclecounter();
+            for (int k = 0; k < 64; k++) { a[64] = (float) k; idx += (int) a[64]; }
+            c1 = __builtin_readcyclecounter();
+            F.dbg[6] = (c1 - c0) / 64 + (idx & 0);
+        }
+#endif
         /* rows of the basis states (input/basis.c:61-114, input/read.c:219-340) */
         for (int s = 0; s < F.basis_states; s++) {
             F.final_d[s] = F.b_final[s];

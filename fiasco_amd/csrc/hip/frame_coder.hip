@@ -41,7 +41,7 @@
 #define BIGF    3.0e38f
 #define MIN_NORM 2e-3f
 
-enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND };
+enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
        PH_AFTER_APPEND };
 
@@ -117,7 +117,7 @@ struct Sh {
     MPState  mp;
     float    blockmin[NBLOCKMIN];
     float    pixels[1024];
-    unsigned long long tk[5];      /* ticks per op (lane 0) */
+    unsigned long long tk[6];      /* ticks per op (lane 0) */
     /* term lists of the state being appended (uniform for the whole workgroup) */
     int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2];
     float    gs_w[2][MAXED + 1];
@@ -298,17 +298,22 @@ __device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int l
                 msk[l] = k != RANGE_ ? 1u : 0u;
                 idx[l][0] = k != RANGE_ ? k : 0;
                 wt[l][0] = 1.0f;
+                /* all edge slots are read unconditionally (independent, coalesced loads; what
+                 * lies behind the terminator is ignored): no load waits for another */
+                int   rd[MAXED];
+                float rw[MAXED];
+#pragma unroll
+                for (int e = 0; e < MAXED; e++) { rd[e] = INTO(F, s, l, e); rw[e] = WEIGHT(F, s, l, e); }
                 bool live = true;
 #pragma unroll
                 for (int e = 0; e < MAXED; e++) {
-                    int d = live ? INTO(F, s, l, e) : NOEDGE;
-                    live = live && d != NOEDGE;
-                    idx[l][e + 1] = live ? d : 0;
-                    wt[l][e + 1] = live ? WEIGHT(F, s, l, e) : 0.0f;
+                    live = live && rd[e] != NOEDGE;
+                    idx[l][e + 1] = live ? rd[e] : 0;
+                    wt[l][e + 1] = live ? rw[e] : 0.0f;
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
-            constexpr int JG = 2;          /* slots per group: 2 x 12 gathers in flight per lane */
+            constexpr int JG = 4;          /* slots per group: 4 x 12 gathers in flight per lane */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
                 float v[JG][2][MAXED + 1];
 #pragma unroll
@@ -373,19 +378,32 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
         if (y < F.height && x < F.width) v = (float) (F.pix16[(size_t) y * F.width + x] / 16);
         sh.pixels[i] = v;
     }
+    unsigned long long tq0 = wall_clock64();
     __syncthreads();
+    if (tid == 0) F.dbg[0] += wall_clock64() - tq0;
+    tq0 = wall_clock64();
     /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
     for (int slot = tid; slot < F.NS; slot += B) {
         int depth = 31 - __clz(slot + 1);
         int lv = level - depth, size = 1 << lv;
         int adr = slot + 1 - (1 << depth);
         float nrm = 0;
-        for (int k = 0; k < size; k++) { float p = sh.pixels[adr * size + k]; nrm += p * p; }
+        const float *px = sh.pixels + adr * size;
+        for (int k = 0; k < size; k += 8) {        /* size >= 64: 8 LDS reads in flight, */
+            float p0 = px[k], p1 = px[k + 1], p2 = px[k + 2], p3 = px[k + 3];   /* adds stay */
+            float p4 = px[k + 4], p5 = px[k + 5], p6 = px[k + 6], p7 = px[k + 7]; /* sequential */
+            nrm += p0 * p0; nrm += p1 * p1; nrm += p2 * p2; nrm += p3 * p3;
+            nrm += p4 * p4; nrm += p5 * p5; nrm += p6 * p6; nrm += p7 * p7;
+        }
         F.norms[slot] = nrm;
     }
+    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[1] += t - tq0; tq0 = t; }
     op_d5(F, sh, 0, sh.states);
+    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[2] += t - tq0; tq0 = t; }
     __syncthreads();
+    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[3] += t - tq0; tq0 = t; }
     op_ipis(F, sh, 0, 0, level, 0);
+    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[4] += t - tq0; tq0 = t; }
     if (tid == 0) {
         F.bytes_img += (unsigned long long) sh.states * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
         F.n_blocks++;
@@ -431,13 +449,16 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
                 m2[l] = k != RANGE_ ? 1u : 0u;
                 i2[l][0] = k != RANGE_ ? k : 0;
                 w2[l][0] = 1.0f;
+                int   rd[MAXED];
+                float rw[MAXED];
+#pragma unroll
+                for (int e = 0; e < MAXED; e++) { rd[e] = INTO(F, t, l, e); rw[e] = WEIGHT(F, t, l, e); }
                 bool live = true;
 #pragma unroll
                 for (int e = 0; e < MAXED; e++) {
-                    int d = live ? INTO(F, t, l, e) : NOEDGE;
-                    live = live && d != NOEDGE;
-                    i2[l][e + 1] = live ? d : 0;
-                    w2[l][e + 1] = live ? WEIGHT(F, t, l, e) : 0.0f;
+                    live = live && rd[e] != NOEDGE;
+                    i2[l][e + 1] = live ? rd[e] : 0;
+                    w2[l][e + 1] = live ? rw[e] : 0.0f;
                     m2[l] |= live ? (2u << e) : 0u;
                 }
             }
@@ -869,12 +890,15 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         r.max_costs = MAXCOSTS;
         r.phase = PH_ENTER;
         sh.sp = 0;
-        serial_advance(F, sh);
+        sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */
     }
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
-    if (tid == 0) for (int k = 0; k < 5; k++) tk[k] = 0;
+    if (tid == 0) for (int k = 0; k < 6; k++) tk[k] = 0;
     unsigned long long t_begin = wall_clock64();
+    /* everything below is inlined into this one loop (a single call site per op keeps the
+     * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
+     * table accesses are global_load, not flat_load through a generic reference) */
     for (;;) {
         __syncthreads();
         const int op = sh.op;
@@ -885,9 +909,10 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         case OP_APPROX:     op_approx(F, sh); break;
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
+        default: break;                      /* OP_NOP */
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {                       /* partition search, lane 0 */
             unsigned long long t1 = wall_clock64();
             tk[op] += t1 - t0;
             serial_advance(F, sh);

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 #include <vector>
 #include "fa_host.h"
 #include "frame_coder.h"
@@ -85,10 +86,12 @@ extern "C" void fiasco_amd_release_memory(void)
 
 struct Layout {
     size_t gram, diag, ipis, d5, img, imgT, norms, num, den, est, ipdo, used, tree, into, weight,
-           final_d, level_of_state, domain_type, x, y, pool_states, pos, pix16, total;
+           final_d, level_of_state, domain_type, x, y, pool_states, pos, hits, pix16, total;
 };
 
-static Layout make_layout(int P, int NL, int NS, int NA, int NI, int il, size_t npix)
+/* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
+ * states of a colour frame never own tables) */
+static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, size_t npix)
 {
     Layout L;
     size_t o = 0;
@@ -106,16 +109,17 @@ static Layout make_layout(int P, int NL, int NS, int NA, int NI, int il, size_t 
     CARVE(ipdo, (size_t) FC_MAXED * P * 4);
     CARVE(used, (size_t) P);
     /* tree .. y are downloaded with ONE copy: keep them adjacent */
-    CARVE(tree, (size_t) 2 * P * 2);
-    CARVE(into, (size_t) 12 * P * 2);
-    CARVE(weight, (size_t) 12 * P * 4);
-    CARVE(final_d, (size_t) P * 4);
-    CARVE(level_of_state, (size_t) P);
-    CARVE(domain_type, (size_t) P);
-    CARVE(x, (size_t) 2 * P * 2);
-    CARVE(y, (size_t) 2 * P * 2);
+    CARVE(tree, (size_t) 2 * PA * 2);
+    CARVE(into, (size_t) 12 * PA * 2);
+    CARVE(weight, (size_t) 12 * PA * 4);
+    CARVE(final_d, (size_t) PA * 4);
+    CARVE(level_of_state, (size_t) PA);
+    CARVE(domain_type, (size_t) PA);
+    CARVE(x, (size_t) 2 * PA * 2);
+    CARVE(y, (size_t) 2 * PA * 2);
     CARVE(pool_states, (size_t) (P + 8) * 2);
-    CARVE(pos, (size_t) (P + 8) * 2);
+    CARVE(pos, (size_t) (PA + 8) * 2);
+    CARVE(hits, (size_t) (PA + 8) * 4);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -125,7 +129,10 @@ static Layout make_layout(int P, int NL, int NS, int NA, int NI, int il, size_t 
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
-    if (job->image->color) { snprintf(why, n, "colour frames are not supported by the device coder yet"); return 0; }
+    if (job->image->color && cp->chroma_max_states > 63) {
+        snprintf(why, n, "device coder supports chroma dictionaries of at most 63 states");
+        return 0;
+    }
     if (cp->images_level != 5 || cp->lc_min_level <= cp->images_level) {
         snprintf(why, n, "device coder needs images_level 5 and min block level > 5 (CLI -z 0 levels)");
         return 0;
@@ -149,7 +156,7 @@ struct FrameSlot {
     int      job;            /* index into jobs[] */
     char    *base = nullptr;
     size_t   bytes = 0;
-    int      P = 0;
+    int      P = 0, PA = 0;
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false;
@@ -182,7 +189,11 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.ML = (int) cp->limit_level;
     F.rpf_mant = (int) cp->rpf.mantissa_bits; F.dc_mant = (int) cp->dc_rpf.mantissa_bits;
     F.rpf_range = cp->rpf.range; F.dc_range = cp->dc_rpf.range;
-    F.P = fs.P;
+    F.P = fs.P; F.PA = fs.PA;
+    F.color = job->image->color ? 1 : 0;
+    F.chroma_max = (int) cp->chroma_max_states;
+    F.chroma_decrease = cp->chroma_decrease;
+    F.plane = (unsigned long long) job->image->width * job->image->height;
     F.NL = (int) (cp->lc_max_level - cp->images_level + 1);
     F.NS = (int) fa_size_of_tree(cp->products_level);
     F.NA = 1 << (cp->lc_max_level - cp->images_level);
@@ -218,6 +229,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.x = (uint16_t *) (base + L.x); F.y = (uint16_t *) (base + L.y);
     F.pool_states = (int16_t *) (base + L.pool_states);
     F.pos = (int16_t *) (base + L.pos);
+    F.hits = (int *) (base + L.hits);
 }
 
 /* allocate the slab of one frame for capacity fs.P and upload its pixel plane */
@@ -231,7 +243,8 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     int NA = 1 << (cp->lc_max_level - cp->images_level);
     int NI = (int) fa_size_of_tree(cp->images_level);
     size_t npix = (size_t) job->image->width * job->image->height;
-    fs.L = make_layout(fs.P, NL, NS, NA, NI, il, npix);
+    const int bands = job->image->color ? 3 : 1;
+    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, npix * bands);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     if (!fs.base) {
         snprintf(job->errmsg, sizeof job->errmsg, "out of HBM: frame needs %.2f GiB", fs.L.total / 1073741824.0);
@@ -243,12 +256,13 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         slab_release(fs.base, fs.bytes); fs.base = nullptr;
         return 0;
     }
-    if (hipMemcpyAsync(fs.base + fs.L.pix16, job->image->pixels[0], npix * 2, hipMemcpyHostToDevice,
-                       S->stream) != hipSuccess) {
-        snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
-        slab_release(fs.base, fs.bytes); fs.base = nullptr;
-        return 0;
-    }
+    for (int b = 0; b < bands; b++)
+        if (hipMemcpyAsync(fs.base + fs.L.pix16 + (size_t) b * npix * 2, job->image->pixels[b], npix * 2,
+                           hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
+            slab_release(fs.base, fs.bytes); fs.base = nullptr;
+            return 0;
+        }
     fs.staged = true;
     return 1;
 }
@@ -297,6 +311,10 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         FrameSlot fs;
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
+        /* colour: the two chroma bands add auxiliary states (no tables) */
+        size_t cap = align_up(cp->limit_states, 64);
+        fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
+        if (fs.PA < fs.P) fs.PA = fs.P;
         S->slots.push_back(fs);
     }
     /* stage as many frames as HBM holds; the rest is staged by run() as slabs free up */
@@ -320,7 +338,7 @@ static int collect(Staged *S, FrameSlot &fs)
     fa_job *job = &S->jobs[fs.job];
     const DevFrame &F = fs.F;
     const Layout &L = fs.L;
-    const int P = fs.P;
+    const int P = fs.PA;                 /* pitch of the automaton arrays */
     fa_wfa *w = job->wfa;
     unsigned ns = (unsigned) F.states;
     size_t span = L.pool_states - L.tree;
@@ -362,7 +380,38 @@ static int collect(Staged *S, FrameSlot &fs)
     job->stats[0].costs = F.costs; job->stats[0].err = F.err;
     job->stats[0].tree_bits = F.tree_bits; job->stats[0].matrix_bits = F.matrix_bits;
     job->stats[0].weights_bits = F.weights_bits;
-    job->lc_min_level_out = job->cp.lc_min_level;
+    if (F.color) {
+        for (int b = 0; b < 2; b++) {
+            job->stats[b + 1].costs = F.c_costs[b]; job->stats[b + 1].err = F.c_err[b];
+            job->stats[b + 1].tree_bits = F.c_tree_bits[b];
+            job->stats[b + 1].matrix_bits = F.c_matrix_bits[b];
+            job->stats[b + 1].weights_bits = F.c_weights_bits[b];
+        }
+        /* co-located luminance states (codec/subdivide.c:167-173,560-567): a pure function of
+         * the finished trees -- walk each chroma tree next to the luminance tree.  The root is
+         * {{Y, Cb}, {Cr, -}} (codec/coder.c:803-833). */
+        int ycb = FA_TREE(w, ns - 1, 0), crs = FA_TREE(w, ns - 1, 1);
+        int roots[2] = { FA_TREE(w, ycb, 1), FA_TREE(w, crs, 0) };
+        int yroot = FA_TREE(w, ycb, 0);
+        std::vector<std::pair<int, int>> stack;
+        for (int b = 0; b < 2; b++) {
+            stack.push_back(std::make_pair(roots[b], yroot));
+            while (!stack.empty()) {
+                std::pair<int, int> t = stack.back();
+                stack.pop_back();
+                int s = t.first, y = t.second;
+                if (s == FA_RANGE || (unsigned) s < w->basis_states) continue;
+                for (int l = 0; l < 2; l++) {
+                    int ny = y != FA_RANGE ? FA_TREE(w, y, l) : FA_RANGE;
+                    w->y_state[s * 2 + l] = (int16_t) ny;
+                    for (int e = 0; FA_INTO(w, s, l, e) != FA_NO_EDGE; e++)
+                        if (FA_INTO(w, s, l, e) == ny) w->y_column[s * 2 + l] = 1;
+                    stack.push_back(std::make_pair((int) FA_TREE(w, s, l), ny));
+                }
+            }
+        }
+    }
+    job->lc_min_level_out = (unsigned) F.lc_min_out;
     job->status = 1;
     g_stats.frames += 1;
     g_stats.bytes_mp += F.bytes_mp; g_stats.bytes_img += F.bytes_img; g_stats.bytes_gram += F.bytes_gram;
@@ -461,12 +510,15 @@ extern "C" int fa_core_run(void *h)
             fs.F = hf[b];
             fs.F.trace = (FcTrace *) tr_keep; fs.F.trace_cap = 0;
             size_t cap = align_up(job->cp.limit_states, 64);
-            if (st == FC_ERR_CAPACITY && (size_t) fs.P < cap) {
+            if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
                 /* capacity guess too small: bigger slab, same inputs, encode again */
                 size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
+                size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
                 slab_release(fs.base, fs.bytes);
                 fs.base = nullptr; fs.staged = false;
                 fs.P = (int) (np > cap ? cap : np);
+                fs.PA = (int) (npa > cap ? cap : npa);
+                if (fs.PA < fs.P) fs.PA = fs.P;
                 if (!stage_slot(S, fs)) fs.done = true;
                 continue;
             }

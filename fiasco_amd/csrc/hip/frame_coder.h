@@ -3,7 +3,8 @@
  *  kernel and its host launcher).  One persistent workgroup encodes one frame; all tables
  *  of that frame live in one HBM slab described by DevFrame.
  *
- *  HBM layout per frame (P = pitch = state capacity rounded up to 64):
+ *  HBM layout per frame (P = pitch = capacity for states that own tables, PA = capacity of the
+ *  automaton arrays; PA > P only for colour frames, whose chroma states are all auxiliary):
  *    gram   [NL][P][P] f32  symmetric <state,state> tables, level images_level..lc_max
  *                           (reference ip_states_state, codec/cwfa.h:86, is lower
  *                           triangular per level; stored full so that both the
@@ -15,7 +16,7 @@
  *    img    [P][NI]    f32  state images levels 0..images_level (reference layout)
  *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
  *    num/den/est [P], ipdo [MAXED][P], used [P]   matching-pursuit scratch
- *    tree [2][P] i16, into [2][6][P] i16, weight [2][6][P] f32, ...  automaton, SoA
+ *    tree [2][PA] i16, into [2][6][PA] i16, weight [2][6][PA] f32, ...  automaton, SoA
  *  Nothing in the slab needs host-side initialisation: the kernel writes every cell before
  *  it reads it (the basis automaton travels inside DevFrame).
  */
@@ -41,7 +42,12 @@ typedef struct DevFrame {
     int      pool_max, limit_states, ML;
     int      rpf_mant, dc_mant;
     float    rpf_range, dc_range;
-    int      P;            /* pitch / state capacity */
+    int      P;            /* pitch / capacity of the per-state TABLES (states with images) */
+    int      PA;           /* pitch / capacity of the automaton arrays (all states, PA >= P) */
+    int      color;        /* 3 bands Y, Cb, Cr (codec/coder.c:775-800) */
+    int      chroma_max;   /* size of the chroma domain list (rle_chroma, domain-pool.c:854-879) */
+    float    chroma_decrease;
+    unsigned long long plane;   /* pixels per band plane in pix16 */
     int      NL, NS, NA, NI;
     int      coeff_size, coeff_nt, dcs, sy;
     int      basis_states;
@@ -62,10 +68,13 @@ typedef struct DevFrame {
     uint16_t *x, *y;
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
+    int     *hits;         /* [P] edge-target histogram for the chroma domain list */
     /* ---- results ---- */
     int      status;
     int      states, root_state;
-    float    costs, err, tree_bits, matrix_bits, weights_bits;
+    float    costs, err, tree_bits, matrix_bits, weights_bits;      /* band 0 (gray / Y) */
+    float    c_costs[2], c_err[2], c_tree_bits[2], c_matrix_bits[2], c_weights_bits[2];  /* Cb, Cr */
+    int      lc_min_out;   /* min block level after the frame (codec/coder.c:785-797 ratchet) */
     /* ---- counters for the roofline model ---- */
     unsigned long long bytes_mp, bytes_img, bytes_gram;
     unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;

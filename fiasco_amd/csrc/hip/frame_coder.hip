@@ -41,7 +41,7 @@
 #define BIGF    3.0e38f
 #define MIN_NORM 2e-3f
 
-enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP };
+enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
        PH_AFTER_APPEND };
 
@@ -64,6 +64,7 @@ struct SFrame {
     Pool  pool0, pool_lc;
     float max_costs, lincomb, subdiv, ret, price;
     int   label, states, phase;
+    int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
 };
 
 struct MPState {
@@ -76,6 +77,7 @@ struct MPState {
     short psorted[MAXED + 1];
     int   np;
     float wb_dc, wb_nd, norm, ab, price, max_costs;
+    int   y_state, ypos;         /* usable co-located luminance state / its list position, or -1 */
     /* best candidate of the running step */
     float b_cost, b_mbits, b_wbits, b_err, b_f[MAXED];
     int   b_index;
@@ -94,6 +96,7 @@ struct __attribute__((aligned(16))) CoeffBuf {
 struct RoundBox {                    /* mp_reg.inc: winner of the running step, in LDS */
     float m;                         /* running min_costs */
     int   state;                     /* winning state or -1 */
+    int   idx;                       /* its list position (list-based scan only) */
     float cost, mbits, wbits, err, f[MAXED];
     float num, den, ip[MAXED - 1];
     unsigned evals, blockevals;
@@ -117,7 +120,12 @@ struct Sh {
     MPState  mp;
     float    blockmin[NBLOCKMIN];
     float    pixels[1024];
-    unsigned long long tk[6];      /* ticks per op (lane 0) */
+    unsigned long long tk[8];      /* ticks per op (lane 0) */
+    /* colour frames (codec/coder.c:775-800): band being coded, its dynamic minimum block
+     * level, root states of the finished bands, states that own tables (= end of Y band) */
+    int      band, lc_min, tree_band[3], ystates, after_chroma;
+    short    dl[64];               /* candidate list of a chroma call: pool + luminance state */
+    unsigned long long red[B / 64];
     /* term lists of the state being appended (uniform for the whole workgroup) */
     int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2];
     float    gs_w[2][MAXED + 1];
@@ -203,9 +211,9 @@ __device__ float pool_bits_sorted(const short *sorted, int nn, const Sh &sh)
 /* ------------------------------------------------------------------ table access */
 
 #define GRAM(F, q)   ((F).gram + (size_t) (q) * (F).P * (F).P)
-#define TREE(F, s, l)        ((F).tree[(l) * (F).P + (s)])
-#define INTO(F, s, l, e)     ((F).into[((l) * 6 + (e)) * (F).P + (s)])
-#define WEIGHT(F, s, l, e)   ((F).weight[((l) * 6 + (e)) * (F).P + (s)])
+#define TREE(F, s, l)        ((F).tree[(l) * (F).PA + (s)])
+#define INTO(F, s, l, e)     ((F).into[((l) * 6 + (e)) * (F).PA + (s)])
+#define WEIGHT(F, s, l, e)   ((F).weight[((l) * 6 + (e)) * (F).PA + (s)])
 
 /* one Gram entry at table level q >= 1 from level q-1 (codec/ip.c:213-257) */
 __device__ float gram_entry(const DevFrame &F, int q, int s1, int s2)
@@ -271,12 +279,15 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 
 /* ------------------------------------------------------------------ parallel ops */
 
+/* states that can own tables: chroma states are all auxiliary (codec/subdivide.c:433-436) */
+__device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.ystates : sh.states; }
+
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
 __device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
 {
-    const int tid = threadIdx.x, il = F.images_level, P = F.P, states = sh.states;
+    const int tid = threadIdx.x, il = F.images_level, P = F.P, states = table_states(sh);
     for (int lv = il + 1; lv <= level; lv++) {
         int delta = level - lv;
         int cnt = 1 << delta;
@@ -367,6 +378,7 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
+    const int16_t *plane = F.pix16 + (size_t) sh.band * F.plane;
     for (int i = tid; i < npx; i += B) {
         unsigned xo = 0, yo = 0;
         for (int b = 0; b < 13; b++) {
@@ -375,13 +387,10 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
         }
         int x = x0 + (int) xo, y = y0 + (int) yo;
         float v = 0;
-        if (y < F.height && x < F.width) v = (float) (F.pix16[(size_t) y * F.width + x] / 16);
+        if (y < F.height && x < F.width) v = (float) (plane[(size_t) y * F.width + x] / 16);
         sh.pixels[i] = v;
     }
-    unsigned long long tq0 = wall_clock64();
     __syncthreads();
-    if (tid == 0) F.dbg[0] += wall_clock64() - tq0;
-    tq0 = wall_clock64();
     /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
     for (int slot = tid; slot < F.NS; slot += B) {
         int depth = 31 - __clz(slot + 1);
@@ -397,15 +406,11 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
         }
         F.norms[slot] = nrm;
     }
-    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[1] += t - tq0; tq0 = t; }
-    op_d5(F, sh, 0, sh.states);
-    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[2] += t - tq0; tq0 = t; }
+    op_d5(F, sh, 0, table_states(sh));
     __syncthreads();
-    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[3] += t - tq0; tq0 = t; }
     op_ipis(F, sh, 0, 0, level, 0);
-    if (tid == 0) { unsigned long long t = wall_clock64(); F.dbg[4] += t - tq0; tq0 = t; }
     if (tid == 0) {
-        F.bytes_img += (unsigned long long) sh.states * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
+        F.bytes_img += (unsigned long long) table_states(sh) * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
         F.n_blocks++;
     }
 }
@@ -506,6 +511,94 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
     }
 }
 
+/* Start of the chroma bands: rle_chroma (codec/domain-pool.c:854-879) keeps the chroma_max
+ * most referenced states as the domain list -- compute_hits (codec/wfalib.c:182-231): state 0
+ * first, then by edge-target count descending (ties: lower state, the order glibc's stable
+ * qsort leaves), only counts > 0, the kept ones ascending -- and the minimum block level
+ * becomes the finest level the luminance band used (codec/coder.c:785-797). */
+__device__ void op_chroma_pool(DevFrame &F, Sh &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int states = sh.states, to = states - 1;
+    Pool &m = sh.pool;
+    const int maxd = F.chroma_max;
+    if (tid == 0) { sh.lc_min = F.ML; sh.ystates = states; }
+    if (maxd < (int) m.n) {
+        /* histogram in HBM with device-scope atomics; read back past the L1 */
+        for (int d = tid; d < to; d += B) __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        for (int s = F.basis_states + tid; s <= to; s += B)
+            for (int l = 0; l < 2; l++)
+                for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++)
+                    __hip_atomic_fetch_add(&F.hits[d], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        /* lane-private best (count, lowest state) over the states d = 1 + tid, + B, ...; the
+         * reference's counters are int16 (wfalib.c:187): wrap like them */
+        unsigned long long best = 0;
+        for (int d = 1 + tid; d < to; d += B) {
+            int k = (short) __hip_atomic_load(&F.hits[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long pk = ((unsigned long long) (unsigned) k << 32) | (0xffffffffu - (unsigned) d);
+            if (k > 0 && pk > best) best = pk;
+        }
+        int n = maxd < to ? maxd : to, npick = 0;
+        if (n > 0) { if (tid == 0) sh.dl[0] = 0; npick = 1; }
+        unsigned long long *red = sh.red;
+        while (npick < n) {
+            unsigned long long w = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long t = __shfl_xor(w, o);
+                if (t > w) w = t;
+            }
+            if (lane == 0) red[wave] = w;
+            __syncthreads();
+            unsigned long long g = red[0];
+#pragma unroll
+            for (int i = 1; i < B / 64; i++) if (red[i] > g) g = red[i];
+            if (g == 0) break;                           /* no state with a count > 0 left */
+            int d = (int) (0xffffffffu - (unsigned) (g & 0xffffffffu));
+            if (tid == 0) sh.dl[npick] = (short) d;
+            npick++;
+            if (best == g) {                             /* owner: retire it, rescan its share */
+                __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best = 0;
+                for (int dd = 1 + tid; dd < to; dd += B) {
+                    int k = (short) __hip_atomic_load(&F.hits[dd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long pk = ((unsigned long long) (unsigned) k << 32) | (0xffffffffu - (unsigned) dd);
+                    if (k > 0 && pk > best) best = pk;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < npick; i++) {            /* ascending, wfalib.c:226 */
+                short v = sh.dl[i];
+                int j = i;
+                while (j > 0 && sh.dl[j - 1] > v) { sh.dl[j] = sh.dl[j - 1]; j--; }
+                sh.dl[j] = v;
+            }
+            for (int i = 0; i < npick; i++) F.pool_states[i] = sh.dl[i];
+            m.n = (unsigned short) npick;
+        }
+    } else if (tid < (int) m.n) {
+        sh.dl[tid] = F.pool_states[tid];                 /* n <= chroma_max <= 63 */
+    }
+    __syncthreads();
+    if (tid == 0) { m.y_index = 0; m.max_domains = m.n; }
+    for (int s = tid; s < states; s += B) F.pos[s] = -1;
+    /* finest level with a linear combination in the luminance band */
+    int mn = F.ML;
+    for (int s = F.basis_states + tid; s < states; s += B) {
+        int lin = (TREE(F, s, 0) == RANGE_) + (TREE(F, s, 1) == RANGE_);
+        unsigned lv = (unsigned) ((int) F.level_of_state[s] - 1);
+        if (lin && lv < (unsigned) mn) mn = (int) lv;
+    }
+    atomicMin(&sh.lc_min, mn);
+    __syncthreads();
+    if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
+}
+
 #include "mp_device.inc"
 
 /* ------------------------------------------------------------------ serial state machine */
@@ -588,8 +681,8 @@ __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
     for (int l = 0; l < 2; l++) {
         const Range &ch = fr.child[l];
         TREE(F, s, l) = (short) ch.tree;
-        F.x[l * F.P + s] = (uint16_t) ch.x;
-        F.y[l * F.P + s] = (uint16_t) ch.y;
+        F.x[l * F.PA + s] = (uint16_t) ch.x;
+        F.y[l * F.PA + s] = (uint16_t) ch.y;
         short si[MAXED + 1]; float sw[MAXED + 1];
         int ne = 0;
         for (int e = 0; ch.into[e] != NOEDGE; e++) {
@@ -607,12 +700,88 @@ __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
     F.domain_type[s] = aux ? 0 : 2;
 }
 
+/* auxiliary state joining two band trees (codec/coder.c:803-833) */
+__device__ int append_join_state(DevFrame &F, Sh &sh, int t0, int t1, int level)
+{
+    const int s = sh.states;
+    if (s >= F.PA) { sh.failed = FC_ERR_CAPACITY; return 0; }
+    TREE(F, s, 0) = (short) t0; TREE(F, s, 1) = (short) t1;
+    for (int l = 0; l < 2; l++) {
+        INTO(F, s, l, 0) = NOEDGE;
+        F.x[l * F.PA + s] = 0; F.y[l * F.PA + s] = 0;
+    }
+    F.final_d[s] = final_distribution_dev(F, s);
+    F.level_of_state[s] = (uint8_t) level;
+    F.domain_type[s] = 0;
+    F.pos[s] = -1;
+    sh.states++;
+    if (sh.states >= F.limit_states) { sh.failed = FC_ERR_STATES; return 0; }
+    return 1;
+}
+
+__device__ void push_root(DevFrame &F, Sh &sh, int y_state)
+{
+    SFrame &r = sh.st[0];
+    r.rg.x = r.rg.y = r.rg.image = r.rg.address = 0;
+    r.rg.level = F.level; r.rg.tree = RANGE_;
+    for (int i = 0; i <= MAXED; i++) { r.rg.weight[i] = 0; r.rg.into[i] = 0; }
+    r.rg.err = r.rg.tree_bits = r.rg.matrix_bits = r.rg.weights_bits = 0;
+    r.max_costs = MAXCOSTS;
+    r.y_state = y_state;
+    r.phase = PH_ENTER;
+    sh.sp = 0;
+}
+
+/* a band of the frame is finished (codec/coder.c:738-833): record it, start the next one.
+ * Returns 0 when the frame is complete (or has failed). */
+__device__ int band_advance(DevFrame &F, Sh &sh)
+{
+    if (!sh.after_chroma) {
+        const SFrame &r = sh.st[0];
+        const Range &rg = r.rg;
+        const int band = sh.band;
+        if (band == 0) {
+            F.costs = r.ret; F.err = rg.err; F.tree_bits = rg.tree_bits;
+            F.matrix_bits = rg.matrix_bits; F.weights_bits = rg.weights_bits;
+            F.root_state = rg.tree;
+        } else {
+            F.c_costs[band - 1] = r.ret; F.c_err[band - 1] = rg.err;
+            F.c_tree_bits[band - 1] = rg.tree_bits; F.c_matrix_bits[band - 1] = rg.matrix_bits;
+            F.c_weights_bits[band - 1] = rg.weights_bits;
+        }
+        if (sh.failed) return 0;
+        if (rg.tree == RANGE_) { sh.failed = FC_ERR_NOROOT; return 0; }
+        if (!F.color) return 0;
+        sh.tree_band[band] = rg.tree;
+        if (band == 1) {
+            if (!append_join_state(F, sh, sh.tree_band[0], sh.tree_band[1], F.level + 1)) return 0;
+            sh.tree_band[1] = sh.states - 1;             /* from here on: the Y+Cb state */
+        }
+        if (band == 2) {
+            if (!append_join_state(F, sh, sh.tree_band[2], RANGE_, F.level + 1)) return 0;
+            if (!append_join_state(F, sh, sh.tree_band[1], sh.states - 1, F.level + 2)) return 0;
+            F.root_state = sh.states - 1;
+            return 0;
+        }
+        sh.band = band + 1;
+        if (band == 0) { sh.op = OP_CHROMA; sh.after_chroma = 1; return 1; }
+    }
+    sh.after_chroma = 0;
+    sh.op = OP_NOP;
+    push_root(F, sh, sh.tree_band[0]);
+    return 1;
+}
+
 /* advance the partition search until a data-parallel operation is required */
 __device__ void serial_advance(DevFrame &F, Sh &sh)
 {
     const int ML = F.ML;
     for (;;) {
-        if (sh.sp < 0) { sh.op = OP_DONE; return; }
+        if (sh.sp < 0) {
+            if (!band_advance(F, sh)) { sh.op = OP_DONE; return; }
+            if (sh.op == OP_CHROMA) return;
+            continue;
+        }
         SFrame &fr = sh.st[sh.sp];
         switch (fr.phase) {
         case PH_ENTER: {
@@ -623,6 +792,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             if (sh.failed || rg.level < 3) { fr.ret = MAXCOSTS; goto pop; }
             if (rg.x >= F.width || rg.y >= F.height) { fr.ret = 0; goto pop; }
             fr.price = F.price;
+            if (sh.band) fr.price *= F.chroma_decrease;
             fr.phase = PH_AFTER_INIT;
             if (rg.level == F.lc_max) {
                 rg.address = rg.image = 0;
@@ -637,6 +807,8 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             snap_save(F, sh, sh.sp, 0);
             tm_save(sh, sh.sp, ML);
             fr.states = sh.states;
+            for (int l = 0; l < 2; l++)                 /* codec/subdivide.c:167-173 */
+                fr.ny[l] = (sh.band && fr.y_state != RANGE_) ? (int) TREE(F, fr.y_state, l) : RANGE_;
             fr.phase = PH_AFTER_LC;
             if (rg.level <= F.lc_max) {
                 fr.lrange = rg;
@@ -656,7 +828,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             snap_save(F, sh, sh.sp, 1);
             sh.pool = fr.pool0;
             snap_load(F, sh, sh.sp, 0);
-            if (rg.level > F.lc_min) {
+            if (rg.level > sh.lc_min) {
                 Range z;
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
                 for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
@@ -686,7 +858,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
             ch.x = (rr.level & 1) ? rr.x : rr.x + label * (int) width_of_level(rr.level - 1);
             ch.y = (rr.level & 1) ? rr.y + label * (int) height_of_level(rr.level - 1) : rr.y;
             fr.phase = PH_CHILD2;
-            if (label && rr.level <= F.lc_max && sh.states > fr.states) {
+            if (label && rr.level <= F.lc_max && sh.states > fr.states && !sh.band) {
                 sh.op = OP_IPIS_INCR; sh.a0 = ch.image; sh.a1 = ch.address; sh.a2 = ch.level;
                 sh.a3 = fr.states;
                 return;
@@ -702,6 +874,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
                 if (sh.sp + 1 >= FC_MAXDEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
                 SFrame &cf = sh.st[sh.sp + 1];
                 cf.rg = fr.child[fr.label];
+                cf.y_state = fr.ny[fr.label];
                 cf.max_costs = remaining;
                 cf.phase = PH_ENTER;
                 sh.sp++;
@@ -748,9 +921,9 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
                 fr.ret = fr.lincomb;
                 goto pop;
             } else {
-                int aux = rg.x + (int) width_of_level(rg.level) > F.width
+                int aux = sh.band > 0 || rg.x + (int) width_of_level(rg.level) > F.width
                           || rg.y + (int) height_of_level(rg.level) > F.height;
-                if (sh.states >= F.P) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+                if (sh.states >= (sh.band ? F.PA : F.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
                 store_new_state(F, sh, fr, aux);
                 fr.phase = PH_AFTER_APPEND;
                 if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return; }
@@ -882,19 +1055,13 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         for (int i = 1; i < F.coeff_nt; i++) sh.cb.tot[i] = (short) F.sy;
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
-        SFrame &r = sh.st[0];
-        r.rg.x = r.rg.y = r.rg.image = r.rg.address = 0;
-        r.rg.level = F.level; r.rg.tree = RANGE_;
-        for (int i = 0; i <= MAXED; i++) { r.rg.weight[i] = 0; r.rg.into[i] = 0; }
-        r.rg.err = r.rg.tree_bits = r.rg.matrix_bits = r.rg.weights_bits = 0;
-        r.max_costs = MAXCOSTS;
-        r.phase = PH_ENTER;
-        sh.sp = 0;
+        sh.band = 0; sh.lc_min = F.lc_min; sh.after_chroma = 0; sh.ystates = 0;
+        push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */
     }
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
-    if (tid == 0) for (int k = 0; k < 6; k++) tk[k] = 0;
+    if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;
     unsigned long long t_begin = wall_clock64();
     /* everything below is inlined into this one loop (a single call site per op keeps the
      * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
@@ -909,6 +1076,7 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         case OP_APPROX:     op_approx(F, sh); break;
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
+        case OP_CHROMA:     op_chroma_pool(F, sh); break;
         default: break;                      /* OP_NOP */
         }
         __syncthreads();
@@ -925,13 +1093,10 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         F.t_total = wall_clock64() - t_begin;
     }
     if (tid == 0) {
-        const Range &rg = sh.st[0].rg;
+        /* per-band results and the root state were recorded by band_advance() */
         F.states = sh.states;
-        F.root_state = rg.tree;
-        F.costs = sh.st[0].ret;
-        F.err = rg.err; F.tree_bits = rg.tree_bits;
-        F.matrix_bits = rg.matrix_bits; F.weights_bits = rg.weights_bits;
-        F.status = sh.failed ? sh.failed : (rg.tree == RANGE_ ? FC_ERR_NOROOT : FC_OK);
+        F.lc_min_out = sh.lc_min;
+        F.status = sh.failed ? sh.failed : FC_OK;
     }
 }
 

@@ -78,6 +78,10 @@ struct MPState {
     int   np;
     float wb_dc, wb_nd, norm, ab, price, max_costs;
     int   y_state, ypos;         /* usable co-located luminance state / its list position, or -1 */
+    /* per-step uniform parts of the stage-1 position pricing (mp_device.inc, StepCtx) */
+    float s1_pre[MAXED], s1_sfx[MAXED], s1_z0, s1_zy;
+    int   s1_last[MAXED], s1_k[MAXED], s1_thr[MAXED];
+    unsigned s1_cd, s1_has;
     /* best candidate of the running step */
     float b_cost, b_mbits, b_wbits, b_err, b_f[MAXED];
     int   b_index;
@@ -130,6 +134,7 @@ struct Sh {
     int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2];
     float    gs_w[2][MAXED + 1];
     int      states;               /* wfa->states */
+    int      flim;                 /* Gram tables: states below it have mirrored entries */
     int      failed;
 };
 
@@ -262,6 +267,52 @@ __device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
     if (s == t) F.diag[(size_t) q * F.P + s] = v;
 }
 
+/*
+ *  Symmetric Gram tables without scattered writes.  A new state s writes only its ROW
+ *  (entries t <= s, contiguous).  The mirrored entries G[t][s] -- one 4-byte store per
+ *  128-byte line when written directly, i.e. 32x write amplification in HBM -- are produced
+ *  later in blocks of GRAM_FB states by gram_flush(): 128-byte segments, full lines.
+ *  Invariant: with flim = sh.flim, G[a][b] is stored if b <= a or max(a, b) < flim; an entry
+ *  outside that set is read through its mirror image.
+ */
+#define GRAM_FB 32
+
+__device__ __forceinline__ float gram_load(const float *G, int P, int a, int b, int flim)
+{
+    const bool mirror = b > a && b >= flim;
+    return mirror ? G[(size_t) b * P + a] : G[(size_t) a * P + b];
+}
+
+__device__ void gram_flush(const DevFrame &F, Sh &sh, int upto)
+{
+    const int tid = threadIdx.x, P = F.P;
+    int flim = sh.flim;
+    if (upto - flim < GRAM_FB) return;                      /* uniform */
+    __syncthreads();                                        /* the rows are complete */
+    while (upto - flim >= GRAM_FB) {
+        for (int q = 0; q < F.NL; q++) {
+            float *G = GRAM(F, q);
+            for (int t = tid; t < flim + GRAM_FB; t += B) {
+                if (t < flim) {
+                    float v[GRAM_FB];
+#pragma unroll
+                    for (int j = 0; j < GRAM_FB; j++) v[j] = G[(size_t) (flim + j) * P + t];
+                    float4 *dst = (float4 *) (G + (size_t) t * P + flim);
+#pragma unroll
+                    for (int j = 0; j < GRAM_FB / 4; j++)
+                        dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+                } else {
+                    for (int j = t - flim + 1; j < GRAM_FB; j++)
+                        G[(size_t) t * P + flim + j] = G[(size_t) (flim + j) * P + t];
+                }
+            }
+        }
+        flim += GRAM_FB;
+    }
+    __syncthreads();
+    if (tid == 0) sh.flim = flim;
+}
+
 /* state image element (codec/control.c:205-258): level l >= 1, position i */
 __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 {
@@ -285,7 +336,7 @@ __device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
-__device__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
+__device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P, states = table_states(sh);
     for (int lv = il + 1; lv <= level; lv++) {
@@ -374,7 +425,7 @@ __device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 }
 
 /* codec/subdivide.c:504-541,612-644 */
-__device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
+__device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
@@ -416,7 +467,7 @@ __device__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 }
 
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
-__device__ void op_append(DevFrame &F, Sh &sh, int s)
+__device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
@@ -441,6 +492,7 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
             sh.gs_n[l] = m;
         }
         __syncthreads();
+        const int flim = sh.flim;
         for (int t = tid; t <= s; t += B) {
             if (!F.domain_type[t]) continue;
             /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
@@ -467,7 +519,11 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
                     m2[l] |= live ? (2u << e) : 0u;
                 }
             }
-            gram_store(F, 0, s, t, gram_dot(F, s, t));
+            {   /* only the row of s is written here: see gram_flush() */
+                float v0 = gram_dot(F, s, t);
+                GRAM(F, 0)[(size_t) s * P + t] = v0;
+                if (s == t) F.diag[s] = v0;
+            }
             for (int q = 1; q < F.NL; q++) {
                 /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
                  * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply */
@@ -477,11 +533,11 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
                 for (int l = 0; l < 2; l++) {
                     const int na = sh.gs_n[l], ca = sh.gs_c[l];
                     for (int a = 0; a < na; a++) {
-                        const float *row = G + (size_t) sh.gs_idx[l][a] * P;
+                        const int A = sh.gs_idx[l][a];
                         float g[MAXED + 1];
 #pragma unroll
                         for (int b = 0; b <= MAXED; b++)
-                            g[b] = ((m2[l] >> b) & 1u) ? row[i2[l][b]] : 0.0f;
+                            g[b] = ((m2[l] >> b) & 1u) ? gram_load(G, P, A, i2[l][b], flim) : 0.0f;
                         float sum = 0;
                         if (m2[l] & 1u) sum = g[0];
 #pragma unroll
@@ -491,7 +547,8 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
                         else ip += sh.gs_w[l][a] * sum;
                     }
                 }
-                gram_store(F, q, s, t, ip);
+                GRAM(F, q)[(size_t) s * P + t] = ip;
+                if (s == t) F.diag[(size_t) q * P + s] = ip;
             }
         }
     }
@@ -509,6 +566,7 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
         F.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
         F.n_appends++;
     }
+    gram_flush(F, sh, s + 1);
 }
 
 /* Start of the chroma bands: rle_chroma (codec/domain-pool.c:854-879) keeps the chroma_max
@@ -516,7 +574,7 @@ __device__ void op_append(DevFrame &F, Sh &sh, int s)
  * first, then by edge-target count descending (ties: lower state, the order glibc's stable
  * qsort leaves), only counts > 0, the kept ones ascending -- and the minimum block level
  * becomes the finest level the luminance band used (codec/coder.c:785-797). */
-__device__ void op_chroma_pool(DevFrame &F, Sh &sh)
+__device__ __noinline__ void op_chroma_pool(DevFrame &F, Sh &sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int states = sh.states, to = states - 1;
@@ -773,7 +831,7 @@ __device__ int band_advance(DevFrame &F, Sh &sh)
 }
 
 /* advance the partition search until a data-parallel operation is required */
-__device__ void serial_advance(DevFrame &F, Sh &sh)
+__device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
 {
     const int ML = F.ML;
     for (;;) {
@@ -910,6 +968,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
                 snap_load(F, sh, sh.sp, 0);
                 tm_load(sh, sh.sp, ML);
                 sh.states = fr.states;
+                if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
                 fr.ret = MAXCOSTS;
                 goto pop;
             } else if (fr.lincomb < fr.subdiv) {
@@ -918,6 +977,7 @@ __device__ void serial_advance(DevFrame &F, Sh &sh)
                 tm_load(sh, sh.sp, ML);
                 rg = fr.lrange;
                 sh.states = fr.states;
+                if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
                 fr.ret = fr.lincomb;
                 goto pop;
             } else {
@@ -1055,6 +1115,7 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         for (int i = 1; i < F.coeff_nt; i++) sh.cb.tot[i] = (short) F.sy;
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
+        sh.flim = 0;
         sh.band = 0; sh.lc_min = F.lc_min; sh.after_chroma = 0; sh.ystates = 0;
         push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */

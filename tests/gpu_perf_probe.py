@@ -12,7 +12,7 @@ import fiasco_amd
 
 w, h, n, nd = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-lib = fiasco_amd.library()
+lib = fiasco_amd.Library(os.environ["FIASCO_AMD_LIB"]) if os.environ.get("FIASCO_AMD_LIB") else fiasco_amd.library()
 lib.set_verbosity(0)
 if max(w, h) > 2048:
     lib.set_limits(30000, 26)

@@ -1,5 +1,7 @@
+# developer helper: issue counters of the frame kernel for one build (run through gpurun)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $R/gpurun_out/pmc_sq1 -o sq -- python3 $R/tests/gpu_perf_probe.py 1920 1080 1 1 1 > $R/gpurun_out/pmc_sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $R/gpurun_out/pmc_sq768 -o sq -- python3 $R/tests/gpu_perf_probe.py 1920 1080 768 8 1 > $R/gpurun_out/pmc_sq768.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $R/gpurun_out/pmc_tcc768 -o tcc -- python3 $R/tests/gpu_perf_probe.py 1920 1080 768 8 1 > $R/gpurun_out/pmc_tcc768.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT -d $R/gpurun_out/pmc_sqb768 -o sq -- python3 $R/tests/gpu_perf_probe.py 1920 1080 768 8 1 > $R/gpurun_out/pmc_sqb768.log 2>&1
+L=${1:-libfiasco_amd}
+rm -rf $R/gpurun_out/pmc_ic
+FIASCO_AMD_LIB=$R/fiasco_amd/$L.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $R/gpurun_out/pmc_ic -o ic -- python3 $R/tests/gpu_perf_probe.py 1920 1080 768 8 1 > $R/gpurun_out/pmc_ic.log 2>&1
+python3 $R/profiles/summarize_rocpd.py $R/gpurun_out/pmc_ic/*_results.db 2>&1 | grep -E "fiasco.*(SQ_|dur)" | sed 's/fiasco_frame_kernel(DevFrame\*) *//; s/dispatches *1 *sum *//; s/ avg.*//'
+rm -rf $R/gpurun_out/pmc_ic

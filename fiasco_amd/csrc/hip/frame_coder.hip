@@ -63,7 +63,7 @@ struct SFrame {
     Range rg, lrange, rrange, child[2];
     Pool  pool0, pool_lc;
     float max_costs, lincomb, subdiv, ret, price;
-    int   label, states, phase;
+    int   label, states, phase, leaf;
     int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
 };
 
@@ -125,6 +125,10 @@ struct Sh {
     float    blockmin[NBLOCKMIN];
     float    pixels[1024];
     unsigned long long tk[8];      /* ticks per op (lane 0) */
+#ifdef FC_SERIAL_PROFILE
+    unsigned long long tk_ph[8], ph_t0;
+    int      ph_prev;
+#endif
     /* colour frames (codec/coder.c:775-800): band being coded, its dynamic minimum block
      * level, root states of the finished bands, states that own tables (= end of Y band) */
     int      band, lc_min, tree_band[3], ystates, after_chroma;
@@ -283,7 +287,7 @@ __device__ __forceinline__ float gram_load(const float *G, int P, int a, int b, 
     return mirror ? G[(size_t) b * P + a] : G[(size_t) a * P + b];
 }
 
-__device__ void gram_flush(const DevFrame &F, Sh &sh, int upto)
+__device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int upto)
 {
     const int tid = threadIdx.x, P = F.P;
     int flim = sh.flim;
@@ -336,7 +340,7 @@ __device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
-__device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int address, int level, int from)
+__device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P, states = table_states(sh);
     for (int lv = il + 1; lv <= level; lv++) {
@@ -407,7 +411,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &F, Sh &sh, int image, int a
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
-__device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
+__device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to)
 {
     const int tid = threadIdx.x, P = F.P;
     for (int s = from + tid; s < to; s += B) {
@@ -425,7 +429,7 @@ __device__ void op_d5(const DevFrame &F, Sh &sh, int from, int to)
 }
 
 /* codec/subdivide.c:504-541,612-644 */
-__device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
+__device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restrict__ sh, int x0, int y0)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
@@ -467,7 +471,7 @@ __device__ __noinline__ void op_init_range(DevFrame &F, Sh &sh, int x0, int y0)
 }
 
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
-__device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
+__device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
@@ -574,7 +578,7 @@ __device__ __noinline__ void op_append(DevFrame &F, Sh &sh, int s)
  * first, then by edge-target count descending (ties: lower state, the order glibc's stable
  * qsort leaves), only counts > 0, the kept ones ascending -- and the minimum block level
  * becomes the finest level the luminance band used (codec/coder.c:785-797). */
-__device__ __noinline__ void op_chroma_pool(DevFrame &F, Sh &sh)
+__device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int states = sh.states, to = states - 1;
@@ -726,7 +730,7 @@ __device__ float final_distribution_dev(const DevFrame &F, int s)
 
 /* init_new_state (codec/subdivide.c:549-610): store the new state's rows; edge lists are
  * kept sorted by target like append_edge (codec/wfalib.c:233-275) */
-__device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
+__device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, int aux)
 {
     const int s = sh.states;
     F.pos[s] = -1;
@@ -759,7 +763,7 @@ __device__ void store_new_state(DevFrame &F, Sh &sh, SFrame &fr, int aux)
 }
 
 /* auxiliary state joining two band trees (codec/coder.c:803-833) */
-__device__ int append_join_state(DevFrame &F, Sh &sh, int t0, int t1, int level)
+__device__ int append_join_state(DevFrame &__restrict__ F, Sh &__restrict__ sh, int t0, int t1, int level)
 {
     const int s = sh.states;
     if (s >= F.PA) { sh.failed = FC_ERR_CAPACITY; return 0; }
@@ -777,7 +781,7 @@ __device__ int append_join_state(DevFrame &F, Sh &sh, int t0, int t1, int level)
     return 1;
 }
 
-__device__ void push_root(DevFrame &F, Sh &sh, int y_state)
+__device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_state)
 {
     SFrame &r = sh.st[0];
     r.rg.x = r.rg.y = r.rg.image = r.rg.address = 0;
@@ -792,7 +796,7 @@ __device__ void push_root(DevFrame &F, Sh &sh, int y_state)
 
 /* a band of the frame is finished (codec/coder.c:738-833): record it, start the next one.
  * Returns 0 when the frame is complete (or has failed). */
-__device__ int band_advance(DevFrame &F, Sh &sh)
+__device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 {
     if (!sh.after_chroma) {
         const SFrame &r = sh.st[0];
@@ -831,7 +835,7 @@ __device__ int band_advance(DevFrame &F, Sh &sh)
 }
 
 /* advance the partition search until a data-parallel operation is required */
-__device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
+__device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 {
     const int ML = F.ML;
     for (;;) {
@@ -841,6 +845,12 @@ __device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
             continue;
         }
         SFrame &fr = sh.st[sh.sp];
+#ifdef FC_SERIAL_PROFILE
+        {   /* developer profile: ticks per phase of the state machine (previous phase ends here) */
+            unsigned long long t = wall_clock64();
+            sh.tk_ph[sh.ph_prev] += t - sh.ph_t0; sh.ph_t0 = t; sh.ph_prev = fr.phase;
+        }
+#endif
         switch (fr.phase) {
         case PH_ENTER: {
             Range &rg = fr.rg;
@@ -861,9 +871,17 @@ __device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
         }
         case PH_AFTER_INIT: {
             Range &rg = fr.rg;
-            fr.pool0 = sh.pool;
-            snap_save(F, sh, sh.sp, 0);
-            tm_save(sh, sh.sp, ML);
+            /* A range that cannot be subdivided needs no model snapshots at all: a rejected
+             * linear combination leaves every model untouched (codec/approx.c:264-268), an
+             * accepted one is exactly the state to continue from, and the tree model is not
+             * touched without children -- the reference's duplicate/restore pairs
+             * (codec/subdivide.c:188-237,404-468) are no-ops for it. */
+            fr.leaf = rg.level <= sh.lc_min && rg.level <= F.lc_max;
+            if (!fr.leaf) {
+                fr.pool0 = sh.pool;
+                snap_save(F, sh, sh.sp, 0);
+                tm_save(sh, sh.sp, ML);
+            }
             fr.states = sh.states;
             for (int l = 0; l < 2; l++)                 /* codec/subdivide.c:167-173 */
                 fr.ny[l] = (sh.band && fr.y_state != RANGE_) ? (int) TREE(F, fr.y_state, l) : RANGE_;
@@ -882,6 +900,11 @@ __device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
         }
         case PH_AFTER_LC: {
             Range &rg = fr.rg;
+            if (fr.leaf) {
+                fr.subdiv = MAXCOSTS;
+                fr.phase = PH_DECIDE;
+                break;
+            }
             fr.pool_lc = sh.pool;
             snap_save(F, sh, sh.sp, 1);
             sh.pool = fr.pool0;
@@ -963,7 +986,11 @@ __device__ __noinline__ void serial_advance(DevFrame &F, Sh &sh)
         }
         case PH_DECIDE: {
             Range &rg = fr.rg;
-            if (fr.lincomb >= MAXCOSTS && fr.subdiv >= MAXCOSTS) {
+            if (fr.leaf) {                       /* models are already what they have to be */
+                if (fr.lincomb < MAXCOSTS) { rg = fr.lrange; fr.ret = fr.lincomb; }
+                else fr.ret = MAXCOSTS;
+                goto pop;
+            } else if (fr.lincomb >= MAXCOSTS && fr.subdiv >= MAXCOSTS) {
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sh.sp, 0);
                 tm_load(sh, sh.sp, ML);
@@ -1123,6 +1150,9 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
     if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;
+#ifdef FC_SERIAL_PROFILE
+    if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; }
+#endif
     unsigned long long t_begin = wall_clock64();
     /* everything below is inlined into this one loop (a single call site per op keeps the
      * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
@@ -1144,7 +1174,13 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         if (tid == 0) {                       /* partition search, lane 0 */
             unsigned long long t1 = wall_clock64();
             tk[op] += t1 - t0;
+#ifdef FC_SERIAL_PROFILE
+            sh.ph_t0 = t1;
+#endif
             serial_advance(F, sh);
+#ifdef FC_SERIAL_PROFILE
+            { unsigned long long t = wall_clock64(); sh.tk_ph[sh.ph_prev] += t - sh.ph_t0; }
+#endif
             tk[0] += wall_clock64() - t1;
         }
     }
@@ -1152,6 +1188,9 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
         F.t_serial = tk[0]; F.t_init = tk[OP_INIT_RANGE]; F.t_approx = tk[OP_APPROX];
         F.t_ipis = tk[OP_IPIS_INCR]; F.t_append = tk[OP_APPEND];
         F.t_total = wall_clock64() - t_begin;
+#ifdef FC_SERIAL_PROFILE
+        for (int k = 0; k < 8; k++) F.dbg[k] = sh.tk_ph[k];
+#endif
     }
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */

@@ -34,6 +34,9 @@
 #include "frame_coder.h"
 
 #define B       FC_BLOCK
+#ifndef FC_WG_PER_CU
+#define FC_WG_PER_CU 3           /* workgroups (frames) per CU the kernel is built for */
+#endif
 #define MAXED   FC_MAXED
 #define NOEDGE  (-1)
 #define RANGE_  (-1)
@@ -90,10 +93,11 @@ struct MPState {
 /* aac model (coeff.c:190-208): totals first, then the counts, one 16-byte aligned block so
  * that a snapshot is a short run of 128-bit LDS copies */
 struct __attribute__((aligned(16))) CoeffBuf {
-    short tot[32];
+    short tot[16];                 /* coeff_nt <= 16 contexts */
     short cnt[FC_MAXCOEFF];
 };
-#define SNAP_POOL16 928            /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define SNAP_POOL16 840            /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define SNAP_TM_WORDS 2184         /* tree-model snapshots: depth x 4 x MAXLEVEL words */
 #define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
 #define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
 
@@ -116,7 +120,7 @@ struct Sh {
     uint4    snap_pool[SNAP_POOL16];
     int      n16;                  /* uint4 per aac snapshot */
     __attribute__((aligned(16))) unsigned tm[TM_WORDS];
-    __attribute__((aligned(16))) unsigned snap_tm[FC_MAXDEPTH][TM_WORDS];
+    __attribute__((aligned(16))) unsigned snap_tm[SNAP_TM_WORDS];
     float    m0tab[12];
     double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM];
     float    Ltab[MAXED + 1];
@@ -707,12 +711,12 @@ __device__ void snap_load(const DevFrame &F, Sh &sh, int depth, int which)
 
 __device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML)
 {
-    copy16((uint4 *) sh.snap_tm[depth], (const uint4 *) sh.tm, ML);      /* 4*ML words */
+    copy16((uint4 *) (sh.snap_tm + depth * 4 * ML), (const uint4 *) sh.tm, ML);      /* 4*ML words */
 }
 
 __device__ __forceinline__ void tm_load(Sh &sh, int depth, int ML)
 {
-    copy16((uint4 *) sh.tm, (const uint4 *) sh.snap_tm[depth], ML);
+    copy16((uint4 *) sh.tm, (const uint4 *) (sh.snap_tm + depth * 4 * ML), ML);
 }
 
 /* wfalib.c:152-180 */
@@ -1060,7 +1064,7 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
     sh.states = nb;
 }
 
-__global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
+__global__ void __launch_bounds__(B, FC_WG_PER_CU) fiasco_frame_kernel(DevFrame *frames)
 {
     __shared__ Sh sh;
     DevFrame &F = frames[blockIdx.x];
@@ -1133,10 +1137,12 @@ __global__ void __launch_bounds__(B, 3) fiasco_frame_kernel(DevFrame *frames)
             }
         }
         /* aac model, all-ones (coeff.c:297-310) */
-        sh.n16 = (64 + 2 * F.coeff_size + 15) / 16;
-        if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16) sh.failed = FC_ERR_INTERNAL;
+        sh.n16 = (32 + 2 * F.coeff_size + 15) / 16;
+        if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16
+            || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16)
+            sh.failed = FC_ERR_INTERNAL;
         for (int i = 0; i < FC_MAXCOEFF; i++) sh.cb.cnt[i] = 0;
-        for (int i = 0; i < 32; i++) sh.cb.tot[i] = 0;
+        for (int i = 0; i < 16; i++) sh.cb.tot[i] = 0;
         for (int i = 0; i < F.coeff_size; i++) sh.cb.cnt[i] = 1;
         sh.cb.tot[0] = (short) F.dcs;
         for (int i = 1; i < F.coeff_nt; i++) sh.cb.tot[i] = (short) F.sy;

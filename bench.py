@@ -63,6 +63,20 @@ def cpu_baseline(frame_pnm):
     return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "cpu coder unavailable"}
 
 
+def pmc_traffic(frames, w, h):
+    """HBM bytes per launch from the PMC passes of tests/gpu_profile.sh (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs of this same command), committed under profiles/.
+    Counters cannot be collected from inside the timed run; the figure is reported only for
+    the workload it was measured on."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except Exception:
+        return None
+    if (frames, w, h) != (768, 1920, 1080):
+        return None
+    return j["fetch_bytes_per_launch"] + j["write_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +174,7 @@ def main():
                        "stage_seconds_per_batch": t_stage,
                        "parity": "stream md5 of survey frame == reference (%s)" % REF_MD5_SEED1234[:12]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(F, a.width, a.height),
                          "kernel": "fiasco_frame_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
         }

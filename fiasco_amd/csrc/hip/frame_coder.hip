@@ -16,17 +16,20 @@
  *    phase A (all waves)  per candidate d, fused: Gram-Schmidt update of rem_num/rem_den
  *                         against the vector chosen in the previous step + stage-1 cost
  *                         estimate e_d; wave-wide min of e_d per 64-candidate block.
- *    phase B (wave 0)     exact replay of the reference's index-ordered scan with its
+ *    phase B (rounds)     exact replay of the reference's index-ordered scan with its
  *                         running `min_costs`: blocks whose min e_d cannot beat the
- *                         running minimum are skipped; inside a block the survivors'
- *                         true costs are evaluated lane-parallel and accepted in index
- *                         order by ballot/ffs (strict '<', as codec/approx.c:459-462,592).
+ *                         running minimum are skipped; the wave that owns the next block
+ *                         evaluates its survivors' true costs lane-parallel and accepts in
+ *                         index order by ballot/ffs (strict '<', codec/approx.c:459-462,592).
+ *  Per-candidate scratch lives in registers (mp_reg.inc); mp_device.inc holds the rate
+ *  terms, the general (HBM scratch) and the chroma (explicit list) variants of the scan.
  *  All float arithmetic keeps the reference's operation order; this file MUST be built
  *  with -ffp-contract=off (no FMA).  double log2() is evaluated once per call into small
  *  LDS tables (the rate models only ever need log2 of count/total ratios).
  *
- *  Device scope of this build: grayscale I frames, `rle` pool, `adaptive` coefficients,
- *  optimisation level 0, lc_min_level > images_level == 5 (CLI defaults).
+ *  Device scope of this build: gray and colour I frames (bands: codec/coder.c:738-833),
+ *  `rle` pool, `adaptive` coefficients, optimisation level 0, lc_min_level > images_level == 5
+ *  (CLI defaults).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -23,6 +23,16 @@
 #include "libfiasco_amd_hip.h"
 
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, hipStream_t stream);
+extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, hipStream_t stream);
+
+/* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
+ * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
+ * second-domain retry */
+static bool needs_big_variant(const fa_cparams *cp)
+{
+    return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
+           || cp->second_domain_block;
+}
 
 static fiasco_amd_stats g_stats;
 
@@ -85,13 +95,13 @@ extern "C" void fiasco_amd_release_memory(void)
 /* ------------------------------------------------------------------ layout */
 
 struct Layout {
-    size_t gram, diag, ipis, d5, img, imgT, norms, num, den, est, ipdo, used, tree, into, weight,
+    size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, pool_states, pos, hits, pix16, total;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
-static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, size_t npix)
+static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix)
 {
     Layout L;
     size_t o = 0;
@@ -100,8 +110,10 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(diag, (size_t) NL * P * 4);
     CARVE(ipis, (size_t) NS * P * 4);
     CARVE(d5, (size_t) NA * P * 4);
+    CARVE(d4, low ? (size_t) 2 * NA * P * 4 : 0);
     CARVE(img, (size_t) P * NI * 4);
     CARVE(imgT, ((size_t) 1 << il) * P * 4);
+    CARVE(imgT4, low ? ((size_t) 1 << (il - 1)) * P * 4 : 0);
     CARVE(norms, (size_t) NS * 4);
     CARVE(num, (size_t) P * 4);
     CARVE(den, (size_t) P * 4);
@@ -133,15 +145,16 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         snprintf(why, n, "device coder supports chroma dictionaries of at most 63 states");
         return 0;
     }
-    if (cp->images_level != 5 || cp->lc_min_level <= cp->images_level) {
-        snprintf(why, n, "device coder needs images_level 5 and min block level > 5 (CLI -z 0 levels)");
+    if (cp->images_level != 5 || cp->lc_min_level < 4) {
+        snprintf(why, n, "device coder needs images_level 5 and min block level >= 4");
         return 0;
     }
-    if (cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search) {
-        snprintf(why, n, "optimisation levels > 0 are not supported by the device coder yet");
+    if (cp->check_for_underflow || cp->check_for_overflow || cp->full_search) {
+        snprintf(why, n, "optimisation level > 1 (cfiasco -z 3) is not supported by the device coder");
         return 0;
     }
-    if (cp->lc_max_level > 10) { snprintf(why, n, "max block level > 10 is not supported by the device coder yet"); return 0; }
+    if (cp->lc_max_level > 12) { snprintf(why, n, "max block level > 12 is not supported by the device coder"); return 0; }
+    if (cp->max_elements > 5) { snprintf(why, n, "more than 5 vectors per block are not supported"); return 0; }
     if (cp->rpf.mantissa_bits > 5 || cp->dc_rpf.mantissa_bits > 5) {
         snprintf(why, n, "RPF mantissa > 5 bits is not supported by the device coder yet");
         return 0;
@@ -159,7 +172,7 @@ struct FrameSlot {
     int      P = 0, PA = 0;
     Layout   L;
     DevFrame F;
-    bool     staged = false, done = false;
+    bool     staged = false, done = false, big = false;
 };
 
 struct Staged {
@@ -194,7 +207,9 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.chroma_max = (int) cp->chroma_max_states;
     F.chroma_decrease = cp->chroma_decrease;
     F.plane = (unsigned long long) job->image->width * job->image->height;
-    F.NL = (int) (cp->lc_max_level - cp->images_level + 1);
+    F.gl0 = (int) (cp->lc_min_level < cp->images_level ? cp->lc_min_level : cp->images_level);
+    F.NL = (int) cp->lc_max_level - F.gl0 + 1;
+    F.second_domain_block = cp->second_domain_block ? 1 : 0;
     F.NS = (int) fa_size_of_tree(cp->products_level);
     F.NA = 1 << (cp->lc_max_level - cp->images_level);
     F.NI = (int) fa_size_of_tree(cp->images_level);
@@ -217,6 +232,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pix16 = (const int16_t *) (base + L.pix16);
     F.gram = (float *) (base + L.gram); F.diag = (float *) (base + L.diag);
     F.ipis = (float *) (base + L.ipis); F.d5 = (float *) (base + L.d5);
+    F.d4 = (float *) (base + L.d4); F.imgT4 = (float *) (base + L.imgT4);
     F.img = (float *) (base + L.img); F.imgT = (float *) (base + L.imgT);
     F.norms = (float *) (base + L.norms);
     F.num = (float *) (base + L.num); F.den = (float *) (base + L.den);
@@ -238,13 +254,14 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     fa_job *job = &S->jobs[fs.job];
     const fa_cparams *cp = &job->cp;
     int il = (int) cp->images_level;
-    int NL = (int) (cp->lc_max_level - cp->images_level + 1);
+    int low = cp->lc_min_level < cp->images_level;
+    int NL = (int) (cp->lc_max_level - (low ? cp->lc_min_level : cp->images_level) + 1);
     int NS = (int) fa_size_of_tree(cp->products_level);
     int NA = 1 << (cp->lc_max_level - cp->images_level);
     int NI = (int) fa_size_of_tree(cp->images_level);
     size_t npix = (size_t) job->image->width * job->image->height;
     const int bands = job->image->color ? 3 : 1;
-    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, npix * bands);
+    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     if (!fs.base) {
         snprintf(job->errmsg, sizeof job->errmsg, "out of HBM: frame needs %.2f GiB", fs.L.total / 1073741824.0);
@@ -311,6 +328,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         FrameSlot fs;
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
+        fs.big = needs_big_variant(cp);
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
@@ -460,6 +478,15 @@ extern "C" int fa_core_run(void *h)
             if (!any) break;
             continue;
         }
+        /* frames of the default kernel build first, then those of the big build */
+        size_t n_small = 0;
+        {
+            std::vector<size_t> ordered;
+            for (size_t b = 0; b < batch.size(); b++) if (!S->slots[batch[b]].big) ordered.push_back(batch[b]);
+            n_small = ordered.size();
+            for (size_t b = 0; b < batch.size(); b++) if (S->slots[batch[b]].big) ordered.push_back(batch[b]);
+            batch.swap(ordered);
+        }
         std::vector<DevFrame> hf(batch.size());
         FcTrace *d_trace = nullptr;
         const char *trace_path = getenv("FIASCO_AMD_TRACE");
@@ -470,9 +497,11 @@ extern "C" int fa_core_run(void *h)
         }
         bool fail = hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
                                    hipMemcpyHostToDevice, S->stream) != hipSuccess;
-        /* ---- one persistent launch: one workgroup per frame ---- */
+        /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
         fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
-        if (!fail) fc_launch(S->d_frames, (unsigned) batch.size(), S->stream);
+        if (!fail && n_small) fc_launch(S->d_frames, (unsigned) n_small, S->stream);
+        if (!fail && batch.size() > n_small)
+            fc_launch_big(S->d_frames + n_small, (unsigned) (batch.size() - n_small), S->stream);
         fail = fail || hipGetLastError() != hipSuccess;
         fail = fail || hipEventRecord(S->ev1, S->stream) != hipSuccess;
         fail = fail || hipStreamSynchronize(S->stream) != hipSuccess;

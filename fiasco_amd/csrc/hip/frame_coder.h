@@ -15,6 +15,7 @@
  *    d5     [NA][P]    f32  level-images_level dots of the current block, address major
  *    img    [P][NI]    f32  state images levels 0..images_level (reference layout)
  *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
+ *    d4, imgT4             the same one level lower, only when min block level is 4
  *    num/den/est [P], ipdo [MAXED][P], used [P]   matching-pursuit scratch
  *    tree [2][PA] i16, into [2][6][PA] i16, weight [2][6][PA] f32, ...  automaton, SoA
  *  Nothing in the slab needs host-side initialisation: the kernel writes every cell before
@@ -38,6 +39,8 @@ typedef struct DevFrame {
     /* ---- parameters ---- */
     float    price;
     int      lc_min, lc_max, images_level, max_elements;
+    int      gl0;          /* lowest level with a Gram table: min(lc_min, images_level) */
+    int      second_domain_block;   /* codec/approx.c:103-118 (cfiasco -z 2) */
     int      level, width, height;
     int      pool_max, limit_states, ML;
     int      rpf_mant, dc_mant;
@@ -60,6 +63,7 @@ typedef struct DevFrame {
     /* ---- tables ---- */
     const int16_t *pix16;
     float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;
+    float   *d4, *imgT4;   /* level images_level-1 twins of d5 / imgT (block levels down to 4) */
     float   *num, *den, *est, *ipdo;
     uint8_t *used;
     int16_t *tree, *into;

@@ -37,8 +37,26 @@
 #include "frame_coder.h"
 
 #define B       FC_BLOCK
+/* Two builds of this file (csrc/Makefile): the default one for the CLI's -z 0 geometry (block
+ * levels 6..10, <= 3 vectors: 3 frames per CU) and FC_VARIANT_BIG for everything else the
+ * device supports (block levels 4..12, <= 5 vectors, second-domain retry: 2 frames per CU). */
+#ifndef FC_VARIANT_BIG
+#define FC_VARIANT_BIG 0
+#endif
+#if FC_VARIANT_BIG
+#define FC_KERNEL    fiasco_frame_kernel_big
+#define FC_LAUNCH    fc_launch_big
+#define FC_PIXELS    4096        /* 2^lc_max, lc_max <= 12 */
+#define FC_NIP       4           /* orthogonal vectors kept per candidate: max_elements - 1 */
+#define FC_WG_PER_CU 2
+#else
+#define FC_KERNEL    fiasco_frame_kernel
+#define FC_LAUNCH    fc_launch
+#define FC_PIXELS    1024
+#define FC_NIP       2
 #ifndef FC_WG_PER_CU
 #define FC_WG_PER_CU 3           /* workgroups (frames) per CU the kernel is built for */
+#endif
 #endif
 #define MAXED   FC_MAXED
 #define NOEDGE  (-1)
@@ -84,6 +102,10 @@ struct MPState {
     int   np;
     float wb_dc, wb_nd, norm, ab, price, max_costs;
     int   y_state, ypos;         /* usable co-located luminance state / its list position, or -1 */
+#if FC_VARIANT_BIG
+    const float *numrow;         /* <range, state> row of the call: ipis slot, d5 or d4 address */
+    int   excl;                  /* list position excluded from this run or -1 */
+#endif
     /* per-step uniform parts of the stage-1 position pricing (mp_device.inc, StepCtx) */
     float s1_pre[MAXED], s1_sfx[MAXED], s1_z0, s1_zy;
     int   s1_last[MAXED], s1_k[MAXED], s1_thr[MAXED];
@@ -99,8 +121,13 @@ struct __attribute__((aligned(16))) CoeffBuf {
     short tot[16];                 /* coeff_nt <= 16 contexts */
     short cnt[FC_MAXCOEFF];
 };
-#define SNAP_POOL16 840            /* uint4 slots for aac snapshots: depth x 2 x n16 */
-#define SNAP_TM_WORDS 2184         /* tree-model snapshots: depth x 4 x MAXLEVEL words */
+#if FC_VARIANT_BIG
+#define SNAP_POOL16 1290           /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define SNAP_TM_WORDS 2392         /* tree-model snapshots: depth x 4 x MAXLEVEL words */
+#else
+#define SNAP_POOL16 840
+#define SNAP_TM_WORDS 2184
+#endif
 #define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
 #define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
 
@@ -129,8 +156,11 @@ struct Sh {
     float    Ltab[MAXED + 1];
     float    Q0, Q1;
     MPState  mp;
+#if FC_VARIANT_BIG
+    MPState  mp_keep;              /* result of the first run (second_domain_block) */
+#endif
     float    blockmin[NBLOCKMIN];
-    float    pixels[1024];
+    float    pixels[FC_PIXELS];
     unsigned long long tk[8];      /* ticks per op (lane 0) */
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tk_ph[8], ph_t0;
@@ -269,6 +299,18 @@ __device__ float gram_dot(const DevFrame &F, int s1, int s2)
         ip += F.imgT[(size_t) k * F.P + s1] * F.imgT[(size_t) k * F.P + s2];
     return ip;
 }
+
+#if FC_VARIANT_BIG
+/* the same one level lower (block levels down to 4) */
+__device__ float gram_dot4(const DevFrame &F, int s1, int s2)
+{
+    const int n = 1 << (F.images_level - 1);
+    float ip = 0;
+    for (int k = 0; k < n; k++)
+        ip += F.imgT4[(size_t) k * F.P + s1] * F.imgT4[(size_t) k * F.P + s2];
+    return ip;
+}
+#endif
 
 __device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
 {
@@ -432,6 +474,18 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
             for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * v[k];
             F.d5[(size_t) a * P + s] = ip;
         }
+#if FC_VARIANT_BIG
+        if (F.gl0 < F.images_level) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = F.imgT4[(size_t) k * P + s];
+            for (int a = 0; a < 2 * F.NA; a++) {
+                float ip = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v[k];
+                F.d4[(size_t) a * P + s] = ip;
+            }
+        }
+#endif
     }
 }
 
@@ -490,6 +544,9 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         float v = image_elem(F, s, l, pos);
         F.img[(size_t) s * F.NI + i + 1] = v;
         if (l == il) F.imgT[(size_t) pos * P + s] = v;
+#if FC_VARIANT_BIG
+        if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) pos * P + s] = v;
+#endif
     }
     __syncthreads();
     /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
@@ -530,12 +587,22 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                     m2[l] |= live ? (2u << e) : 0u;
                 }
             }
-            {   /* only the row of s is written here: see gram_flush() */
-                float v0 = gram_dot(F, s, t);
-                GRAM(F, 0)[(size_t) s * P + t] = v0;
-                if (s == t) F.diag[s] = v0;
+            /* only the row of s is written here: see gram_flush() */
+            int q1 = 1;
+#if FC_VARIANT_BIG
+            if (F.gl0 < il) {                      /* levels <= images_level: direct dots */
+                float v4 = gram_dot4(F, s, t);
+                GRAM(F, 0)[(size_t) s * P + t] = v4;
+                if (s == t) F.diag[s] = v4;
+                q1 = 2;
             }
-            for (int q = 1; q < F.NL; q++) {
+#endif
+            {
+                float v0 = gram_dot(F, s, t);
+                GRAM(F, q1 - 1)[(size_t) s * P + t] = v0;
+                if (s == t) F.diag[(size_t) (q1 - 1) * P + s] = v0;
+            }
+            for (int q = q1; q < F.NL; q++) {
                 /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
                  * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply */
                 const float *G = GRAM(F, q - 1);
@@ -568,6 +635,14 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * F.imgT[(size_t) k * P + s];
         F.d5[(size_t) a * P + s] = ip;
     }
+#if FC_VARIANT_BIG
+    if (F.gl0 < il)
+        for (int a = tid; a < 2 * F.NA; a += B) {
+            float ip = 0;
+            for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * F.imgT4[(size_t) k * P + s];
+            F.d4[(size_t) a * P + s] = ip;
+        }
+#endif
     if (tid == 0) {
         int E = 0;
         for (int l = 0; l < 2; l++) {
@@ -1057,17 +1132,27 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
                 float v = image_elem(F, s, l, i);
                 F.img[(size_t) s * F.NI + (1 << l) - 1 + i] = v;
                 if (l == il) F.imgT[(size_t) i * F.P + s] = v;
+#if FC_VARIANT_BIG
+                if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) i * F.P + s] = v;
+#endif
             }
     for (int q = 0; q < F.NL; q++)
         for (int s1 = 0; s1 < nb; s1++)
             for (int s2 = 0; s2 <= s1; s2++) {
                 if (!F.domain_type[s2]) continue;
+#if FC_VARIANT_BIG
+                if (F.gl0 < il) {
+                    gram_store(F, q, s1, s2, q == 0 ? gram_dot4(F, s1, s2) : q == 1 ? gram_dot(F, s1, s2)
+                                                                   : gram_entry(F, q, s1, s2));
+                    continue;
+                }
+#endif
                 gram_store(F, q, s1, s2, q == 0 ? gram_dot(F, s1, s2) : gram_entry(F, q, s1, s2));
             }
     sh.states = nb;
 }
 
-__global__ void __launch_bounds__(B, FC_WG_PER_CU) fiasco_frame_kernel(DevFrame *frames)
+__global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
 {
     __shared__ Sh sh;
     DevFrame &F = frames[blockIdx.x];
@@ -1209,7 +1294,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) fiasco_frame_kernel(DevFrame 
     }
 }
 
-extern "C" void fc_launch(DevFrame *d_frames, unsigned n, hipStream_t stream)
+extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fiasco_frame_kernel, dim3(n), dim3(B), 0, stream, d_frames);
+    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames);
 }

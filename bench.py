@@ -130,8 +130,12 @@ def main():
     barrier()
     lib.reset_stats()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = batch.encode()
+    # K passes, pipelined: the device search of pass i+1 is started before the host writes
+    # the .fco streams of pass i (fiasco_amd_batch_submit / _collect); every pass is complete
+    # -- kernel, automaton download, entropy writer -- when the timed region ends
+    batch.submit()
+    for i in range(a.steps):
+        out = batch.collect(resubmit=i + 1 < a.steps)
     barrier()
     dt = time.perf_counter() - t0
     st = lib.get_stats()

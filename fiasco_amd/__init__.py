@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect",
     "fiasco_amd_release_memory",
 ]
 
@@ -205,6 +206,10 @@ class Batch:
         L.fiasco_amd_batch_encode.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]
         L.fiasco_amd_batch_encode.restype = c.c_int
         L.fiasco_amd_batch_free.argtypes = [c.c_void_p]
+        L.fiasco_amd_batch_submit.argtypes = [c.c_void_p]
+        L.fiasco_amd_batch_submit.restype = c.c_int
+        L.fiasco_amd_batch_collect.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t), c.c_int]
+        L.fiasco_amd_batch_collect.restype = c.c_int
         self.lib = lib
         self.n = len(pnm_list)
         bufs = (c.c_char_p * self.n)(*pnm_list)
@@ -214,10 +219,23 @@ class Batch:
         if not self.handle:
             raise FiascoError(lib.error_message())
 
+    def submit(self):
+        """fiasco_amd_batch_submit: start a pass over the resident inputs, do not wait."""
+        return self.lib.L.fiasco_amd_batch_submit(self.handle)
+
+    def collect(self, resubmit=False):
+        """fiasco_amd_batch_collect: streams of the submitted pass; with resubmit the next pass
+        is started before the host writes them (writer of pass i overlaps search of pass i+1)."""
+        return self._run(lambda outs, olen: self.lib.L.fiasco_amd_batch_collect(
+            self.handle, outs, olen, 1 if resubmit else 0))
+
     def encode(self):
+        return self._run(lambda outs, olen: self.lib.L.fiasco_amd_batch_encode(self.handle, outs, olen))
+
+    def _run(self, call):
         outs = (ctypes.c_void_p * self.n)()
         olen = (ctypes.c_size_t * self.n)()
-        self.lib.L.fiasco_amd_batch_encode(self.handle, outs, olen)
+        call(outs, olen)
         res = []
         for i in range(self.n):
             if outs[i]:

@@ -184,6 +184,15 @@ struct Staged {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ok = false;
     char err[200] = "";
+    /* launch in flight (fa_core_submit .. fa_core_finish) */
+    std::vector<size_t>   batch;
+    std::vector<DevFrame> hf;
+    FcTrace *d_trace = nullptr;
+    bool inflight = false, launch_failed = false, broken = false;
+    int  good = 0;
+    std::vector<std::pair<size_t, size_t>> to_unpack;   /* (slot, offset in pinned) */
+    char  *pinned = nullptr;       /* host staging buffer for the automaton downloads */
+    size_t pinned_bytes = 0;
 };
 
 static void fill_frame(FrameSlot &fs, const fa_job *job)
@@ -288,9 +297,14 @@ extern "C" void fa_core_unstage(void *h)
 {
     Staged *S = (Staged *) h;
     if (!S) return;
+    if (S->inflight) {                       /* a submitted launch nobody collected */
+        (void) hipStreamSynchronize(S->stream);
+        if (S->d_trace) (void) hipFree(S->d_trace);
+    }
     for (size_t k = 0; k < S->slots.size(); k++)
         if (S->slots[k].base) slab_release(S->slots[k].base, S->slots[k].bytes);
     if (S->d_frames) (void) hipFree(S->d_frames);
+    if (S->pinned) (void) hipHostFree(S->pinned);
     if (S->ev0) (void) hipEventDestroy(S->ev0);
     if (S->ev1) (void) hipEventDestroy(S->ev1);
     if (S->stream) (void) hipStreamDestroy(S->stream);
@@ -351,7 +365,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
 }
 
 /* copy the finished automaton of one frame back into the job's fa_wfa */
-static int collect(Staged *S, FrameSlot &fs)
+static int collect(Staged *S, FrameSlot &fs, const char *pinned)
 {
     fa_job *job = &S->jobs[fs.job];
     const DevFrame &F = fs.F;
@@ -360,11 +374,16 @@ static int collect(Staged *S, FrameSlot &fs)
     fa_wfa *w = job->wfa;
     unsigned ns = (unsigned) F.states;
     size_t span = L.pool_states - L.tree;
-    std::vector<char> host(span);
-    if (hipMemcpy(host.data(), fs.base + L.tree, span, hipMemcpyDeviceToHost) != hipSuccess) {
-        snprintf(job->errmsg, sizeof job->errmsg, "HIP error: automaton download failed");
-        return 0;
+    std::vector<char> own;
+    if (!pinned) {                       /* no staging buffer: plain synchronous copy */
+        own.resize(span);
+        if (hipMemcpy(own.data(), fs.base + L.tree, span, hipMemcpyDeviceToHost) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: automaton download failed");
+            return 0;
+        }
+        pinned = own.data();
     }
+    struct { const char *p; const char *data() const { return p; } } host = { pinned };
     const int16_t *tree = (const int16_t *) (host.data());
     const int16_t *into = (const int16_t *) (host.data() + (L.into - L.tree));
     const float *weight = (const float *) (host.data() + (L.weight - L.tree));
@@ -442,129 +461,229 @@ static int collect(Staged *S, FrameSlot &fs)
     return 1;
 }
 
-extern "C" int fa_core_run(void *h)
+/* build the next launch from the frames that are staged and not yet encoded, upload their
+ * descriptors and start the kernel(s); nothing is waited for.  Returns false when there is
+ * nothing to launch. */
+static bool launch_wave(Staged *S)
 {
-    Staged *S = (Staged *) h;
-    int good = 0;
-    if (!S || !S->ok) return 0;
-    for (size_t k = 0; k < S->slots.size(); k++) {
-        S->slots[k].done = false;
-        S->jobs[S->slots[k].job].status = 0;
+    std::vector<size_t> &batch = S->batch;
+    batch.clear();
+    for (size_t k = 0; k < S->slots.size(); k++)
+        if (S->slots[k].staged && !S->slots[k].done) batch.push_back(k);
+    if (batch.empty()) return false;
+    /* frames of the default kernel build first, then those of the big build */
+    size_t n_small = 0;
+    {
+        std::vector<size_t> ordered;
+        for (size_t b = 0; b < batch.size(); b++) if (!S->slots[batch[b]].big) ordered.push_back(batch[b]);
+        n_small = ordered.size();
+        for (size_t b = 0; b < batch.size(); b++) if (S->slots[batch[b]].big) ordered.push_back(batch[b]);
+        batch.swap(ordered);
     }
-    for (;;) {
-        /* frames staged and not yet encoded form the next launch */
-        std::vector<size_t> batch;
-        for (size_t k = 0; k < S->slots.size(); k++)
-            if (S->slots[k].staged && !S->slots[k].done) batch.push_back(k);
-        if (batch.empty()) {
-            /* stage a later wave (frames that did not fit while others held their slabs):
-             * finished frames give their slabs back first (they are re-staged by the next
-             * run() if the batch is encoded again) */
-            bool any = false, pending = false;
-            for (size_t k = 0; k < S->slots.size(); k++) {
-                FrameSlot &fs = S->slots[k];
-                if (!fs.staged && !fs.done && !S->jobs[fs.job].errmsg[0]) pending = true;
-            }
-            if (!pending) break;
-            for (size_t k = 0; k < S->slots.size(); k++) {
-                FrameSlot &fs = S->slots[k];
-                if (fs.done && fs.base) { slab_release(fs.base, fs.bytes); fs.base = nullptr; fs.staged = false; }
-            }
-            for (size_t k = 0; k < S->slots.size(); k++) {
-                FrameSlot &fs = S->slots[k];
-                if (fs.staged || fs.done || S->jobs[fs.job].errmsg[0]) continue;
-                if (stage_slot(S, fs)) any = true; else break;
-            }
-            if (!any) break;
-            continue;
+    std::vector<DevFrame> &hf = S->hf;
+    hf.resize(batch.size());
+    S->d_trace = nullptr;
+    const char *trace_path = getenv("FIASCO_AMD_TRACE");
+    const int trace_cap = 400000;
+    for (size_t b = 0; b < batch.size(); b++) hf[b] = S->slots[batch[b]].F;
+    if (trace_path && hipMalloc((void **) &S->d_trace, sizeof(FcTrace) * trace_cap) == hipSuccess) {
+        hf[0].trace = S->d_trace; hf[0].trace_cap = trace_cap;
+    }
+    bool fail = hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
+                               hipMemcpyHostToDevice, S->stream) != hipSuccess;
+    /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
+    fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
+    if (!fail && n_small) fc_launch(S->d_frames, (unsigned) n_small, S->stream);
+    if (!fail && batch.size() > n_small)
+        fc_launch_big(S->d_frames + n_small, (unsigned) (batch.size() - n_small), S->stream);
+    fail = fail || hipGetLastError() != hipSuccess;
+    fail = fail || hipEventRecord(S->ev1, S->stream) != hipSuccess;
+    S->launch_failed = fail;
+    return true;
+}
+
+/* wait for the launch, download the descriptors, collect every finished frame; a frame whose
+ * capacity guess was too small gets a bigger slab and stays "not done" for the next launch */
+static void complete_wave(Staged *S)
+{
+    std::vector<size_t> &batch = S->batch;
+    std::vector<DevFrame> &hf = S->hf;
+    bool fail = S->launch_failed;
+    fail = fail || hipStreamSynchronize(S->stream) != hipSuccess;
+    if (!fail) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, S->ev0, S->ev1) == hipSuccess) {
+            g_stats.kernel_ms += ms;
+            g_stats.launches += 1;
         }
-        /* frames of the default kernel build first, then those of the big build */
-        size_t n_small = 0;
-        {
-            std::vector<size_t> ordered;
-            for (size_t b = 0; b < batch.size(); b++) if (!S->slots[batch[b]].big) ordered.push_back(batch[b]);
-            n_small = ordered.size();
-            for (size_t b = 0; b < batch.size(); b++) if (S->slots[batch[b]].big) ordered.push_back(batch[b]);
-            batch.swap(ordered);
+        fail = hipMemcpy(hf.data(), S->d_frames, sizeof(DevFrame) * batch.size(),
+                         hipMemcpyDeviceToHost) != hipSuccess;
+    }
+    const char *trace_path = getenv("FIASCO_AMD_TRACE");
+    if (S->d_trace && !fail && trace_path) {
+        std::vector<FcTrace> tr((size_t) hf[0].trace_n);
+        if (hipMemcpy(tr.data(), S->d_trace, sizeof(FcTrace) * tr.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE *tf = fopen(trace_path, "wb");
+            if (tf) { fwrite(tr.data(), sizeof(FcTrace), tr.size(), tf); fclose(tf); }
         }
-        std::vector<DevFrame> hf(batch.size());
-        FcTrace *d_trace = nullptr;
-        const char *trace_path = getenv("FIASCO_AMD_TRACE");
-        const int trace_cap = 400000;
-        for (size_t b = 0; b < batch.size(); b++) hf[b] = S->slots[batch[b]].F;
-        if (trace_path && hipMalloc((void **) &d_trace, sizeof(FcTrace) * trace_cap) == hipSuccess) {
-            hf[0].trace = d_trace; hf[0].trace_cap = trace_cap;
-        }
-        bool fail = hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
-                                   hipMemcpyHostToDevice, S->stream) != hipSuccess;
-        /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
-        fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
-        if (!fail && n_small) fc_launch(S->d_frames, (unsigned) n_small, S->stream);
-        if (!fail && batch.size() > n_small)
-            fc_launch_big(S->d_frames + n_small, (unsigned) (batch.size() - n_small), S->stream);
-        fail = fail || hipGetLastError() != hipSuccess;
-        fail = fail || hipEventRecord(S->ev1, S->stream) != hipSuccess;
-        fail = fail || hipStreamSynchronize(S->stream) != hipSuccess;
-        if (!fail) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, S->ev0, S->ev1) == hipSuccess) {
-                g_stats.kernel_ms += ms;
-                g_stats.launches += 1;
-            }
-            fail = hipMemcpy(hf.data(), S->d_frames, sizeof(DevFrame) * batch.size(),
-                             hipMemcpyDeviceToHost) != hipSuccess;
-        }
-        if (d_trace && !fail) {
-            std::vector<FcTrace> tr((size_t) hf[0].trace_n);
-            if (hipMemcpy(tr.data(), d_trace, sizeof(FcTrace) * tr.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-                FILE *tf = fopen(trace_path, "wb");
-                if (tf) { fwrite(tr.data(), sizeof(FcTrace), tr.size(), tf); fclose(tf); }
-            }
-        }
-        if (d_trace) (void) hipFree(d_trace);
-        if (fail) {
-            for (size_t b = 0; b < batch.size(); b++) {
-                FrameSlot &fs = S->slots[batch[b]];
-                snprintf(S->jobs[fs.job].errmsg, sizeof S->jobs[fs.job].errmsg, "HIP error: %s",
-                         hipGetErrorString(hipGetLastError()));
-                fs.done = true;
-            }
-            break;
-        }
+    }
+    if (S->d_trace) { (void) hipFree(S->d_trace); S->d_trace = nullptr; }
+    if (fail) {
         for (size_t b = 0; b < batch.size(); b++) {
             FrameSlot &fs = S->slots[batch[b]];
-            fa_job *job = &S->jobs[fs.job];
-            int st = hf[b].status;
-            void *tr_keep = fs.F.trace;
-            fs.F = hf[b];
-            fs.F.trace = (FcTrace *) tr_keep; fs.F.trace_cap = 0;
-            size_t cap = align_up(job->cp.limit_states, 64);
-            if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
-                /* capacity guess too small: bigger slab, same inputs, encode again */
-                size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
-                size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
-                slab_release(fs.base, fs.bytes);
-                fs.base = nullptr; fs.staged = false;
-                fs.P = (int) (np > cap ? cap : np);
-                fs.PA = (int) (npa > cap ? cap : npa);
-                if (fs.PA < fs.P) fs.PA = fs.P;
-                if (!stage_slot(S, fs)) fs.done = true;
-                continue;
-            }
+            snprintf(S->jobs[fs.job].errmsg, sizeof S->jobs[fs.job].errmsg, "HIP error: %s",
+                     hipGetErrorString(hipGetLastError()));
             fs.done = true;
-            if (st == FC_OK) {
-                good += collect(S, fs);
-            } else {
-                const char *msg = "device coder failed";
-                if (st == FC_ERR_STATES || st == FC_ERR_CAPACITY) msg = "Maximum number of states reached!";
-                else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
-                else if (st == FC_ERR_INTERNAL) msg = "device coder: recursion depth exceeded";
-                snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
-            }
         }
-        (void) hipStreamSynchronize(S->stream);
+        S->broken = true;
+        return;
     }
-    return good;
+    /* all automata of the launch come down with async copies into one pinned buffer */
+    std::vector<size_t> off(batch.size(), (size_t) -1);
+    {
+        size_t need = 0;
+        for (size_t b = 0; b < batch.size(); b++)
+            if (hf[b].status == FC_OK) {
+                const Layout &L = S->slots[batch[b]].L;
+                off[b] = need;
+                need += align_up(L.pool_states - L.tree, 256);
+            }
+        if (need > S->pinned_bytes) {
+            if (S->pinned) (void) hipHostFree(S->pinned);
+            S->pinned = nullptr; S->pinned_bytes = 0;
+            if (hipHostMalloc((void **) &S->pinned, need, hipHostMallocDefault) == hipSuccess) S->pinned_bytes = need;
+            else { S->pinned = nullptr; (void) hipGetLastError(); }
+        }
+        if (S->pinned) {
+            for (size_t b = 0; b < batch.size(); b++)
+                if (off[b] != (size_t) -1) {
+                    const FrameSlot &fs = S->slots[batch[b]];
+                    if (hipMemcpyAsync(S->pinned + off[b], fs.base + fs.L.tree, fs.L.pool_states - fs.L.tree,
+                                       hipMemcpyDeviceToHost, S->stream) != hipSuccess)
+                        off[b] = (size_t) -1;
+                }
+            (void) hipStreamSynchronize(S->stream);
+        }
+    }
+    for (size_t b = 0; b < batch.size(); b++) {
+        FrameSlot &fs = S->slots[batch[b]];
+        fa_job *job = &S->jobs[fs.job];
+        int st = hf[b].status;
+        void *tr_keep = fs.F.trace;
+        fs.F = hf[b];
+        fs.F.trace = (FcTrace *) tr_keep; fs.F.trace_cap = 0;
+        size_t cap = align_up(job->cp.limit_states, 64);
+        if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
+            /* capacity guess too small: bigger slab, same inputs, encode again */
+            size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
+            size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
+            slab_release(fs.base, fs.bytes);
+            fs.base = nullptr; fs.staged = false;
+            fs.P = (int) (np > cap ? cap : np);
+            fs.PA = (int) (npa > cap ? cap : npa);
+            if (fs.PA < fs.P) fs.PA = fs.P;
+            if (!stage_slot(S, fs)) fs.done = true;
+            continue;
+        }
+        fs.done = true;
+        if (st == FC_OK) {
+            /* unpacking into the job's fa_wfa is host work on host memory: deferred so that
+             * a following submit can start the device first (flush_unpack) */
+            if (S->pinned && off[b] != (size_t) -1) S->to_unpack.push_back(std::make_pair(batch[b], off[b]));
+            else S->good += collect(S, fs, nullptr);
+        } else {
+            const char *msg = "device coder failed";
+            if (st == FC_ERR_STATES || st == FC_ERR_CAPACITY) msg = "Maximum number of states reached!";
+            else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
+            else if (st == FC_ERR_INTERNAL) msg = "device coder: recursion depth exceeded";
+            snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
+        }
+    }
+    (void) hipStreamSynchronize(S->stream);
+}
+
+static void flush_unpack(Staged *S)
+{
+    for (size_t i = 0; i < S->to_unpack.size(); i++)
+        S->good += collect(S, S->slots[S->to_unpack[i].first], S->pinned + S->to_unpack[i].second);
+    S->to_unpack.clear();
+}
+
+/* start encoding every staged frame; returns immediately (the kernel runs) */
+extern "C" int fa_core_submit(void *h)
+{
+    Staged *S = (Staged *) h;
+    if (!S || !S->ok) return 0;
+    if (S->inflight) return 1;
+    /* job status / automata of the previous pass stay readable until fa_core_finish() */
+    for (size_t k = 0; k < S->slots.size(); k++) S->slots[k].done = false;
+    S->good = 0; S->broken = false;
+    S->inflight = launch_wave(S);
+    return 1;
+}
+
+/* wait for the submitted launch and bring every frame to completion (re-encodes with larger
+ * slabs, later waves of a batch that did not fit into HBM at once).  After it returns the
+ * jobs' automata are in host memory and the device is free for the next submit. */
+extern "C" int fa_core_finish2(void *h, int resubmit)
+{
+    Staged *S = (Staged *) h;
+    if (!S || !S->ok) return 0;
+    if (!S->inflight) { fa_core_submit(h); }
+    for (size_t k = 0; k < S->slots.size(); k++) S->jobs[S->slots[k].job].status = 0;
+    for (;;) {
+        if (S->inflight) { complete_wave(S); S->inflight = false; if (S->broken) break; }
+        {   /* anything left to encode (bigger slabs, later waves)?  then the staging buffer
+             * is needed again: unpack first */
+            bool more = false;
+            for (size_t k = 0; k < S->slots.size(); k++) if (!S->slots[k].done) more = true;
+            if (more) flush_unpack(S);
+        }
+        if (launch_wave(S)) { S->inflight = true; continue; }
+        /* stage a later wave (frames that did not fit while others held their slabs):
+         * finished frames give their slabs back first (they are re-staged by the next
+         * run if the batch is encoded again) */
+        bool any = false, pending = false;
+        for (size_t k = 0; k < S->slots.size(); k++) {
+            FrameSlot &fs = S->slots[k];
+            if (!fs.staged && !fs.done && !S->jobs[fs.job].errmsg[0]) pending = true;
+        }
+        if (!pending) break;
+        for (size_t k = 0; k < S->slots.size(); k++) {
+            FrameSlot &fs = S->slots[k];
+            if (fs.done && fs.base) { slab_release(fs.base, fs.bytes); fs.base = nullptr; fs.staged = false; }
+        }
+        for (size_t k = 0; k < S->slots.size(); k++) {
+            FrameSlot &fs = S->slots[k];
+            if (fs.staged || fs.done || S->jobs[fs.job].errmsg[0]) continue;
+            if (stage_slot(S, fs)) any = true; else break;
+        }
+        if (!any) break;
+    }
+    int good_before = S->good;
+    if (resubmit && !S->broken) {
+        /* next pass on the device first, then the host-side unpacking of this one */
+        std::vector<std::pair<size_t, size_t>> keep;
+        keep.swap(S->to_unpack);
+        fa_core_submit(h);                         /* resets S->good */
+        S->to_unpack.swap(keep);
+        int g = S->good;
+        S->good = good_before;
+        flush_unpack(S);
+        good_before = S->good;
+        S->good = g;
+        return good_before;
+    }
+    flush_unpack(S);
+    return S->good;
+}
+
+extern "C" int fa_core_finish(void *h) { return fa_core_finish2(h, 0); }
+
+extern "C" int fa_core_run(void *h)
+{
+    if (!fa_core_submit(h)) return 0;
+    return fa_core_finish(h);
 }
 
 extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)

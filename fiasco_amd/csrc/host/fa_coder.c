@@ -14,6 +14,8 @@
 #include <ctype.h>
 #include <math.h>
 #include <errno.h>
+#include <pthread.h>
+#include <unistd.h>
 #include "fa_host.h"
 
 static unsigned g_limit_states = FA_STOCK_STATES;
@@ -424,25 +426,87 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
     return b;
 }
 
+/* the entropy writer of every finished frame (output/write.c:53-119 in the reference): a pure
+ * function of the frame's automaton, so the frames of a batch are written by a few host
+ * threads */
+typedef struct { fiasco_amd_batch_t *b; unsigned char **outv; size_t *out_len; unsigned t, nt, good; } wr_task;
+
+static void *wr_thread(void *arg)
+{
+    wr_task *w = (wr_task *) arg;
+    fiasco_amd_batch_t *b = w->b;
+    unsigned i;
+    for (i = w->t; i < b->n; i += w->nt) {
+        fa_bitw out;
+        if (!b->jobs[i].status) continue;
+        fa_bw_init(&out);
+        if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, 0, b->normal_domains,
+                           b->delta_domains, &out)) {
+            w->out_len[i] = fa_bw_finish(&out);
+            w->outv[i] = (unsigned char *) malloc(w->out_len[i]);
+            memcpy(w->outv[i], out.buf, w->out_len[i]);
+            w->good++;
+        }
+        fa_bw_free(&out);
+    }
+    return NULL;
+}
+
+static unsigned write_streams(fiasco_amd_batch_t *b, unsigned char **outv, size_t *out_len)
+{
+    enum { MAXT = 16 };
+    pthread_t th[MAXT];
+    wr_task task[MAXT];
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    unsigned nt = b->n / 16, t, good = 0, i;
+    if (nt > MAXT) nt = MAXT;
+    if (ncpu > 0 && nt > (unsigned) ncpu) nt = (unsigned) ncpu;
+    if (nt < 1) nt = 1;
+    for (t = 0; t < nt; t++) {
+        task[t].b = b; task[t].outv = outv; task[t].out_len = out_len;
+        task[t].t = t; task[t].nt = nt; task[t].good = 0;
+    }
+    {
+        int started[MAXT] = { 0 };
+        for (t = 1; t < nt; t++)
+            started[t] = pthread_create(&th[t], NULL, wr_thread, &task[t]) == 0;
+        wr_thread(&task[0]);
+        for (t = 1; t < nt; t++) {
+            if (started[t]) pthread_join(th[t], NULL);
+            else wr_thread(&task[t]);        /* no thread: the caller does that share */
+        }
+    }
+    for (t = 0; t < nt; t++) good += task[t].good;
+    for (i = 0; i < b->n; i++)
+        if (!b->jobs[i].status) fa_set_error("%s", b->jobs[i].errmsg);
+    return good;
+}
+
+int fiasco_amd_batch_submit(fiasco_amd_batch_t *b)
+{
+    return b ? fa_core_submit(b->staged) : 0;
+}
+
+/* finish the submitted pass; with `resubmit` the next pass over the same resident inputs is
+ * started before the host writes the streams of this one, so that the entropy writer of pass
+ * i overlaps the device search of pass i+1 */
+int fiasco_amd_batch_collect(fiasco_amd_batch_t *b, unsigned char **outv, size_t *out_len, int resubmit)
+{
+    unsigned i, good = 0;
+    if (!b) return 0;
+    for (i = 0; i < b->n; i++) { outv[i] = NULL; out_len[i] = 0; }
+    fa_core_finish2(b->staged, resubmit);          /* the next pass touches device memory only */
+    good = write_streams(b, outv, out_len);
+    return (int) good;
+}
+
 int fiasco_amd_batch_encode(fiasco_amd_batch_t *b, unsigned char **outv, size_t *out_len)
 {
     unsigned i, good = 0;
     if (!b) return 0;
     for (i = 0; i < b->n; i++) { outv[i] = NULL; out_len[i] = 0; }
     fa_core_run(b->staged);
-    for (i = 0; i < b->n; i++) {
-        fa_bitw out;
-        if (!b->jobs[i].status) { fa_set_error("%s", b->jobs[i].errmsg); continue; }
-        fa_bw_init(&out);
-        if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, 0, b->normal_domains,
-                           b->delta_domains, &out)) {
-            out_len[i] = fa_bw_finish(&out);
-            outv[i] = (unsigned char *) malloc(out_len[i]);
-            memcpy(outv[i], out.buf, out_len[i]);
-            good++;
-        }
-        fa_bw_free(&out);
-    }
+    good = write_streams(b, outv, out_len);
     return (int) good;
 }
 

@@ -173,7 +173,13 @@ typedef struct fa_job {
  * jobs[] must stay alive between stage() and unstage(). */
 int   fa_core_encode_frames(unsigned n, fa_job *jobs);
 void *fa_core_stage(unsigned n, fa_job *jobs);
-int   fa_core_run(void *staged);
+int   fa_core_run(void *staged);            /* == submit + finish */
+int   fa_core_submit(void *staged);         /* start encoding all staged frames, do not wait */
+int   fa_core_finish2(void *staged, int resubmit);   /* finish, and start the next pass as
+                                             * early as possible when resubmit != 0 */
+int   fa_core_finish(void *staged);         /* wait, bring every frame to completion; the jobs'
+                                             * automata are then in host memory and the core is
+                                             * free for the next submit */
 void  fa_core_unstage(void *staged);
 const char *fa_core_name(void);
 

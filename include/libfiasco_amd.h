@@ -131,6 +131,14 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
                                            const size_t *pnm_len, float quality,
                                            const fiasco_c_options_t *options);
 int  fiasco_amd_batch_encode(fiasco_amd_batch_t *batch, unsigned char **out, size_t *out_len);
+/* Pipelined form of encode for repeated passes (a stream of batches): submit starts the
+ * device search and returns; collect waits for it, optionally starts the next pass
+ * (resubmit != 0) and then writes the streams of the finished pass on the host, so the
+ * host-side .fco writer (output/write.c in the reference) overlaps the next device pass.
+ * submit + collect(.., 0) == encode. */
+int  fiasco_amd_batch_submit(fiasco_amd_batch_t *batch);
+int  fiasco_amd_batch_collect(fiasco_amd_batch_t *batch, unsigned char **out, size_t *out_len,
+                              int resubmit);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
 
 #ifdef __cplusplus

@@ -1126,3 +1126,8 @@ int fa_core_run(void *h)
 }
 
 void fa_core_unstage(void *h) { free(h); }
+
+/* the CPU oracle has nothing to overlap: submit is a no-op, finish does the work */
+int fa_core_submit(void *h) { return h != NULL; }
+int fa_core_finish(void *h) { return fa_core_run(h); }
+int fa_core_finish2(void *h, int resubmit) { (void) resubmit; return fa_core_run(h); }

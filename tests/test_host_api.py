@@ -165,3 +165,16 @@ def test_unsupported_modes_are_errors_not_silence(oracle, inputs, tmp_path):
     rc = oracle.fiasco_coder([inputs.path("f0_96x64")], str(tmp_path / "v.fco"), 20.0, o)
     assert rc == 0 and "prediction" in oracle.error_message()
     o.delete()
+
+
+def test_submit_collect_on_oracle_seam(oracle, inputs):
+    """The pipelined batch entry points exist above every core (the oracle's submit is a
+    no-op): submit + collect == encode."""
+    import fiasco_amd
+    frames = [inputs.data(n) for n in ("g96x64", "g160x120")]
+    b = fiasco_amd.Batch(oracle, frames, 20.0, oracle.cli_options())
+    ref = b.encode()
+    b.submit()
+    assert b.collect(resubmit=True) == ref
+    assert b.collect() == ref
+    b.free()

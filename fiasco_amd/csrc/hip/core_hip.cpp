@@ -24,6 +24,8 @@
 
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, hipStream_t stream);
 extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, hipStream_t stream);
+extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, hipStream_t stream);
+extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t stream);
 
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
@@ -471,13 +473,23 @@ static bool launch_wave(Staged *S)
     for (size_t k = 0; k < S->slots.size(); k++)
         if (S->slots[k].staged && !S->slots[k].done) batch.push_back(k);
     if (batch.empty()) return false;
-    /* frames of the default kernel build first, then those of the big build */
-    size_t n_small = 0;
+    /* one launch per kernel build (frame_coder.hip): geometry {default, big} x workgroup width
+     * {256, 512 threads}.  The wide builds take launches with no more frames than CUs (the
+     * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
+     * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
+    size_t group_n[4] = { 0, 0, 0, 0 };
     {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus <= 0)
+            cus = 256;
+        const bool few = batch.size() <= (size_t) cus && !getenv("FIASCO_AMD_NO_WIDE");
         std::vector<size_t> ordered;
-        for (size_t b = 0; b < batch.size(); b++) if (!S->slots[batch[b]].big) ordered.push_back(batch[b]);
-        n_small = ordered.size();
-        for (size_t b = 0; b < batch.size(); b++) if (S->slots[batch[b]].big) ordered.push_back(batch[b]);
+        for (int g = 0; g < 4; g++)
+            for (size_t b = 0; b < batch.size(); b++) {
+                const FrameSlot &fs = S->slots[batch[b]];
+                const bool wide = few || fs.P > 12 * 256;
+                if ((int) fs.big * 2 + (int) wide == g) { ordered.push_back(batch[b]); group_n[g]++; }
+            }
         batch.swap(ordered);
     }
     std::vector<DevFrame> &hf = S->hf;
@@ -493,9 +505,15 @@ static bool launch_wave(Staged *S)
                                hipMemcpyHostToDevice, S->stream) != hipSuccess;
     /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
     fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
-    if (!fail && n_small) fc_launch(S->d_frames, (unsigned) n_small, S->stream);
-    if (!fail && batch.size() > n_small)
-        fc_launch_big(S->d_frames + n_small, (unsigned) (batch.size() - n_small), S->stream);
+    {
+        typedef void (*launch_fn)(DevFrame *, unsigned, hipStream_t);
+        static const launch_fn launch[4] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide };
+        size_t first = 0;
+        for (int g = 0; g < 4 && !fail; g++) {
+            if (group_n[g]) launch[g](S->d_frames + first, (unsigned) group_n[g], S->stream);
+            first += group_n[g];
+        }
+    }
     fail = fail || hipGetLastError() != hipSuccess;
     fail = fail || hipEventRecord(S->ev1, S->stream) != hipSuccess;
     S->launch_failed = fail;

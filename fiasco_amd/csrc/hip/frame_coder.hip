@@ -36,7 +36,23 @@
 #include <math.h>
 #include "frame_coder.h"
 
+/* FC_VARIANT_WIDE: 512 threads per frame instead of 256 -- for launches with fewer frames than
+ * CUs x 3 and for frames with more states than 12 x 256 (4K): twice the lanes per frame, 18
+ * register slots per lane (9216 states), one workgroup per CU */
+#ifndef FC_VARIANT_WIDE
+#define FC_VARIANT_WIDE 0
+#endif
+#if FC_VARIANT_WIDE
+#define B       512
+#if defined(FC_VARIANT_BIG) && FC_VARIANT_BIG
+#define FC_KREG 12               /* 6144 states with 4 orthogonal vectors each in registers */
+#else
+#define FC_KREG 18
+#endif
+#else
 #define B       FC_BLOCK
+#define FC_KREG 12
+#endif
 /* Two builds of this file (csrc/Makefile): the default one for the CLI's -z 0 geometry (block
  * levels 6..10, <= 3 vectors: 3 frames per CU) and FC_VARIANT_BIG for everything else the
  * device supports (block levels 4..12, <= 5 vectors, second-domain retry: 2 frames per CU). */
@@ -44,18 +60,28 @@
 #define FC_VARIANT_BIG 0
 #endif
 #if FC_VARIANT_BIG
+#if FC_VARIANT_WIDE
+#define FC_KERNEL    fiasco_frame_kernel_big_wide
+#define FC_LAUNCH    fc_launch_big_wide
+#else
 #define FC_KERNEL    fiasco_frame_kernel_big
 #define FC_LAUNCH    fc_launch_big
+#endif
 #define FC_PIXELS    4096        /* 2^lc_max, lc_max <= 12 */
 #define FC_NIP       4           /* orthogonal vectors kept per candidate: max_elements - 1 */
-#define FC_WG_PER_CU 2
+#define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 2)
+#else
+#if FC_VARIANT_WIDE
+#define FC_KERNEL    fiasco_frame_kernel_wide
+#define FC_LAUNCH    fc_launch_wide
 #else
 #define FC_KERNEL    fiasco_frame_kernel
 #define FC_LAUNCH    fc_launch
+#endif
 #define FC_PIXELS    1024
 #define FC_NIP       2
 #ifndef FC_WG_PER_CU
-#define FC_WG_PER_CU 3           /* workgroups (frames) per CU the kernel is built for */
+#define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 3)   /* workgroups (frames) per CU the kernel is built for */
 #endif
 #endif
 #define MAXED   FC_MAXED

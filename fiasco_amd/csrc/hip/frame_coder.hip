@@ -412,21 +412,107 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 /* states that can own tables: chroma states are all auxiliary (codec/subdivide.c:433-436) */
 __device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.ystates : sh.states; }
 
+/* Out-of-line functions get the frame descriptor through a generic reference, so every table
+ * pointer they read is per-lane data to the compiler (64-bit address arithmetic in VGPRs for
+ * each access).  The pointers ARE uniform: moving them to scalar registers leaves one 32-bit
+ * lane offset per access. */
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ GLOBAL_AS T *uniform_ptr(T *p)
+{
+    unsigned long long v = (unsigned long long) p;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    /* known to be HBM (never LDS/scratch): global_load with a scalar base, not flat_load */
+    return (GLOBAL_AS T *) (((unsigned long long) hi << 32) | lo);
+}
+
+/* element i of a table behind a scalar base: the byte offset is formed in 32 bits so that
+ * the access is `global_load v, v_off, s[base:base+1]` (tables are < 4 GB apart from gram,
+ * which is not accessed this way) */
+template <typename T>
+__device__ __forceinline__ T ldg(GLOBAL_AS const T *base, unsigned i)
+{
+    return *(GLOBAL_AS const T *) ((GLOBAL_AS const char *) base + i * (unsigned) sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ void stg(GLOBAL_AS T *base, unsigned i, T v)
+{
+    *(GLOBAL_AS T *) ((GLOBAL_AS char *) base + i * (unsigned) sizeof(T)) = v;
+}
+
+/* the automaton arrays of a frame behind uniform global pointers */
+struct AutoTabs {
+    GLOBAL_AS const int16_t *tree, *into;
+    GLOBAL_AS const float   *weight;
+    GLOBAL_AS const uint8_t *domain_type;
+    int PA;
+};
+
+__device__ __forceinline__ void auto_tabs(const DevFrame &F, AutoTabs &t)
+{
+    t.tree = uniform_ptr((const int16_t *) F.tree); t.into = uniform_ptr((const int16_t *) F.into);
+    t.weight = uniform_ptr((const float *) F.weight);
+    t.domain_type = uniform_ptr((const uint8_t *) F.domain_type);
+    t.PA = __builtin_amdgcn_readfirstlane(F.PA);
+}
+
+/* the automaton rows of one state as they come out of memory: all edge slots are read
+ * unconditionally (independent, coalesced loads; what lies behind the terminator is ignored) */
+struct EdgeRows {
+    int   tree[2], rd[2][MAXED];
+    float rw[2][MAXED];
+    int   dt;
+};
+
+__device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRows &r)
+{
+    unsigned us = (unsigned) s;
+    /* opaque to loop strength reduction: otherwise every array gets its own 64-bit pointer
+     * induction variable in VGPRs (46 registers) instead of scalar base + this one offset */
+    asm volatile("" : "+v"(us));
+    r.dt = ldg(T.domain_type, us);
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        /* one scalar base per array, the row offset goes into the lane offset */
+        r.tree[l] = ldg(T.tree, us + (unsigned) (l * T.PA));
+#pragma unroll
+        for (int e = 0; e < MAXED; e++) {
+            r.rd[l][e] = ldg(T.into, us + (unsigned) ((l * 6 + e) * T.PA));
+            r.rw[l][e] = ldg(T.weight, us + (unsigned) ((l * 6 + e) * T.PA));
+        }
+    }
+}
+
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
 __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
 {
-    const int tid = threadIdx.x, il = F.images_level, P = F.P, states = table_states(sh);
+    const int tid = threadIdx.x, il = F.images_level;
+    const int P = __builtin_amdgcn_readfirstlane(F.P), states = __builtin_amdgcn_readfirstlane(table_states(sh));
+    image = __builtin_amdgcn_readfirstlane(image); address = __builtin_amdgcn_readfirstlane(address);
+    level = __builtin_amdgcn_readfirstlane(level); from = __builtin_amdgcn_readfirstlane(from);
+    GLOBAL_AS float *const ipis = uniform_ptr(F.ipis);
+    GLOBAL_AS const float *const d5 = uniform_ptr((const float *) F.d5);
+    AutoTabs T;
+    auto_tabs(F, T);
     for (int lv = il + 1; lv <= level; lv++) {
         int delta = level - lv;
         int cnt = 1 << delta;
         int slot0 = ((image + 1) << delta) - 1;
         int adr0 = address << delta;
-        const float *src0 = (lv == il + 1) ? F.d5 + (size_t) (adr0 * 2) * P
-                                           : F.ipis + (size_t) (slot0 * 2 + 1) * P;
-        for (int s = from + tid; s < states; s += B) {
-            if (!F.domain_type[s]) continue;
+        GLOBAL_AS const float *src0 = (lv == il + 1) ? d5 + (size_t) (adr0 * 2) * P
+                                                     : ipis + (size_t) (slot0 * 2 + 1) * P;
+        /* the rows of the NEXT state of this lane are requested before the gathers of the
+         * current one are waited for (one memory round trip per state instead of two) */
+        int s = from + tid;
+        EdgeRows nx;
+        if (s < states) load_edge_rows(T, s, nx);
+        for (; s < states; s += B) {
+            const EdgeRows cur = nx;
+            if (s + B < states) load_edge_rows(T, s + B, nx);
+            if (!cur.dt) continue;
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
              * of a group of slots are in flight together (the chain is latency bound). */
@@ -435,22 +521,16 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
             unsigned msk[2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
-                int k = TREE(F, s, l);
+                int k = cur.tree[l];
                 msk[l] = k != RANGE_ ? 1u : 0u;
                 idx[l][0] = k != RANGE_ ? k : 0;
                 wt[l][0] = 1.0f;
-                /* all edge slots are read unconditionally (independent, coalesced loads; what
-                 * lies behind the terminator is ignored): no load waits for another */
-                int   rd[MAXED];
-                float rw[MAXED];
-#pragma unroll
-                for (int e = 0; e < MAXED; e++) { rd[e] = INTO(F, s, l, e); rw[e] = WEIGHT(F, s, l, e); }
                 bool live = true;
 #pragma unroll
                 for (int e = 0; e < MAXED; e++) {
-                    live = live && rd[e] != NOEDGE;
-                    idx[l][e + 1] = live ? rd[e] : 0;
-                    wt[l][e + 1] = live ? rw[e] : 0.0f;
+                    live = live && cur.rd[l][e] != NOEDGE;
+                    idx[l][e + 1] = live ? cur.rd[l][e] : 0;
+                    wt[l][e + 1] = live ? cur.rw[l][e] : 0.0f;
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
@@ -463,8 +543,12 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     for (int l = 0; l < 2; l++)
 #pragma unroll
                         for (int i = 0; i <= MAXED; i++) {
-                            bool on = ((msk[l] >> i) & 1u) && j0 + jj < cnt;
-                            v[jj][l][i] = on ? src0[(size_t) ((j0 + jj) * 2 + l) * P + idx[l][i]] : 0.0f;
+                            /* UNCONDITIONAL loads (dead terms read element 0 of the row, slots
+                             * past the end re-read the last one): a conditional load becomes a
+                             * branch with its own s_waitcnt and the gathers would run one
+                             * after the other instead of all in flight */
+                            const int jc = j0 + jj < cnt ? j0 + jj : cnt - 1;
+                            v[jj][l][i] = ldg(src0, (unsigned) idx[l][i] + (unsigned) ((jc * 2 + l) * P));
                         }
 #pragma unroll
                 for (int jj = 0; jj < JG; jj++) {
@@ -477,7 +561,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                         for (int i = 1; i <= MAXED; i++)
                             if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
                     }
-                    F.ipis[(size_t) (slot0 + j0 + jj) * P + s] = acc;
+                    stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
                 }
             }
         }
@@ -586,9 +670,17 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             sh.gs_n[l] = m;
         }
         __syncthreads();
-        const int flim = sh.flim;
+        const int flim = __builtin_amdgcn_readfirstlane(sh.flim);
+        const int Pu = __builtin_amdgcn_readfirstlane(P);
+        s = __builtin_amdgcn_readfirstlane(s);
+        GLOBAL_AS float *const gram = uniform_ptr(F.gram);
+        GLOBAL_AS float *const diag = uniform_ptr(F.diag);
+        AutoTabs T;
+        auto_tabs(F, T);
         for (int t = tid; t <= s; t += B) {
-            if (!F.domain_type[t]) continue;
+            EdgeRows rows;
+            load_edge_rows(T, t, rows);
+            if (!rows.dt) continue;
             /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
              * once and reused by every table level */
             int   i2[2][MAXED + 1];
@@ -596,20 +688,16 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             unsigned m2[2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
-                int k = TREE(F, t, l);
+                int k = rows.tree[l];
                 m2[l] = k != RANGE_ ? 1u : 0u;
                 i2[l][0] = k != RANGE_ ? k : 0;
                 w2[l][0] = 1.0f;
-                int   rd[MAXED];
-                float rw[MAXED];
-#pragma unroll
-                for (int e = 0; e < MAXED; e++) { rd[e] = INTO(F, t, l, e); rw[e] = WEIGHT(F, t, l, e); }
                 bool live = true;
 #pragma unroll
                 for (int e = 0; e < MAXED; e++) {
-                    live = live && rd[e] != NOEDGE;
-                    i2[l][e + 1] = live ? rd[e] : 0;
-                    w2[l][e + 1] = live ? rw[e] : 0.0f;
+                    live = live && rows.rd[l][e] != NOEDGE;
+                    i2[l][e + 1] = live ? rows.rd[l][e] : 0;
+                    w2[l][e + 1] = live ? rows.rw[l][e] : 0.0f;
                     m2[l] |= live ? (2u << e) : 0u;
                 }
             }
@@ -618,41 +706,53 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
 #if FC_VARIANT_BIG
             if (F.gl0 < il) {                      /* levels <= images_level: direct dots */
                 float v4 = gram_dot4(F, s, t);
-                GRAM(F, 0)[(size_t) s * P + t] = v4;
-                if (s == t) F.diag[s] = v4;
+                stg(gram, (unsigned) (s * Pu + t), v4);
+                if (s == t) stg(diag, (unsigned) s, v4);
                 q1 = 2;
             }
 #endif
             {
                 float v0 = gram_dot(F, s, t);
-                GRAM(F, q1 - 1)[(size_t) s * P + t] = v0;
-                if (s == t) F.diag[(size_t) (q1 - 1) * P + s] = v0;
+                stg(gram + (size_t) (q1 - 1) * Pu * Pu, (unsigned) (s * Pu + t), v0);
+                if (s == t) stg(diag, (unsigned) ((q1 - 1) * Pu + s), v0);
             }
             for (int q = q1; q < F.NL; q++) {
                 /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
-                 * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply */
-                const float *G = GRAM(F, q - 1);
+                 * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply.
+                 * All gathers of a label (terms(s) x 6 slots of t) are issued before the first
+                 * is used; dead term slots of t read a valid dummy entry (no per-lane branch). */
+                GLOBAL_AS const float *G = gram + (size_t) (q - 1) * Pu * Pu;
                 float ip = 0;
 #pragma unroll
                 for (int l = 0; l < 2; l++) {
-                    const int na = sh.gs_n[l], ca = sh.gs_c[l];
-                    for (int a = 0; a < na; a++) {
-                        const int A = sh.gs_idx[l][a];
-                        float g[MAXED + 1];
+                    const int na = __builtin_amdgcn_readfirstlane(sh.gs_n[l]);
+                    const int ca = __builtin_amdgcn_readfirstlane(sh.gs_c[l]);
+                    float g[MAXED + 1][MAXED + 1];
 #pragma unroll
-                        for (int b = 0; b <= MAXED; b++)
-                            g[b] = ((m2[l] >> b) & 1u) ? gram_load(G, P, A, i2[l][b], flim) : 0.0f;
+                    for (int a = 0; a <= MAXED; a++) {
+                        if (a >= na) break;                            /* uniform */
+                        const int A = __builtin_amdgcn_readfirstlane(sh.gs_idx[l][a]);
+#pragma unroll
+                        for (int b = 0; b <= MAXED; b++) {
+                            const int bb = i2[l][b];
+                            const bool mirror = bb > A && bb >= flim;     /* gram_load() */
+                            g[a][b] = ldg(G, (unsigned) (mirror ? bb * Pu + A : A * Pu + bb));
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a <= MAXED; a++) {
+                        if (a >= na) break;
                         float sum = 0;
-                        if (m2[l] & 1u) sum = g[0];
+                        if (m2[l] & 1u) sum = g[a][0];
 #pragma unroll
                         for (int b = 1; b <= MAXED; b++)
-                            if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[b];
+                            if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[a][b];
                         if (a == 0 && ca) ip += sum;
                         else ip += sh.gs_w[l][a] * sum;
                     }
                 }
-                GRAM(F, q)[(size_t) s * P + t] = ip;
-                if (s == t) F.diag[(size_t) q * P + s] = ip;
+                stg(gram + (size_t) q * Pu * Pu, (unsigned) (s * Pu + t), ip);
+                if (s == t) stg(diag, (unsigned) (q * Pu + s), ip);
             }
         }
     }

@@ -188,6 +188,10 @@ struct Sh {
     float    blockmin[NBLOCKMIN];
     float    pixels[FC_PIXELS];
     unsigned long long tk[8];      /* ticks per op (lane 0) */
+    struct {
+        unsigned long long bytes_mp, bytes_img, bytes_gram, n_mp, n_steps, n_blocks, n_appends,
+                           n_fulleval, n_blockevals, t_mpA, t_mpB;
+    } cnt;                         /* DevFrame counters of the same names */
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tk_ph[8], ph_t0;
     int      ph_prev;
@@ -636,8 +640,8 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     __syncthreads();
     op_ipis(F, sh, 0, 0, level, 0);
     if (tid == 0) {
-        F.bytes_img += (unsigned long long) table_states(sh) * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
-        F.n_blocks++;
+        sh.cnt.bytes_img += (unsigned long long) table_states(sh) * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
+        sh.cnt.n_blocks++;
     }
 }
 
@@ -775,8 +779,8 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             if (TREE(F, s, l) != RANGE_) E++;
             for (int e = 0; INTO(F, s, l, e) != NOEDGE; e++) E++;
         }
-        F.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
-        F.n_appends++;
+        sh.cnt.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
+        sh.cnt.n_appends++;
     }
     gram_flush(F, sh, s + 1);
 }
@@ -1292,10 +1296,12 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         static const unsigned c1[22] = {1,1,1,1,1,1,1,1,1,2,3,5,10,15,20,25,30,35,60,60,60,60};
         sh.failed = 0;
         /* a staged frame may be encoded several times: start from clean counters */
-        F.bytes_mp = F.bytes_img = F.bytes_gram = 0;
-        F.n_mp = F.n_steps = F.n_blocks = F.n_appends = F.n_fulleval = 0;
+        /* the roofline / profile counters are accumulated in LDS (a global read-modify-write
+         * per call is a memory round trip of the serial lane) and stored once at the end */
+        sh.cnt.bytes_mp = sh.cnt.bytes_img = sh.cnt.bytes_gram = 0;
+        sh.cnt.n_mp = sh.cnt.n_steps = sh.cnt.n_blocks = sh.cnt.n_appends = sh.cnt.n_fulleval = 0;
+        sh.cnt.t_mpA = sh.cnt.t_mpB = sh.cnt.n_blockevals = 0;
         F.trace_n = 0;
-        F.t_mpA = F.t_mpB = F.n_blockevals = 0;
         for (int k = 0; k < 8; k++) F.dbg[k] = 0;
 #ifdef FC_LATENCY_PROBE
         {   /* developer probe: dependent-load latency on a small global array (L2 resident)
@@ -1408,6 +1414,10 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         F.t_serial = tk[0]; F.t_init = tk[OP_INIT_RANGE]; F.t_approx = tk[OP_APPROX];
         F.t_ipis = tk[OP_IPIS_INCR]; F.t_append = tk[OP_APPEND];
         F.t_total = wall_clock64() - t_begin;
+        F.bytes_mp = sh.cnt.bytes_mp; F.bytes_img = sh.cnt.bytes_img; F.bytes_gram = sh.cnt.bytes_gram;
+        F.n_mp = sh.cnt.n_mp; F.n_steps = sh.cnt.n_steps; F.n_blocks = sh.cnt.n_blocks;
+        F.n_appends = sh.cnt.n_appends; F.n_fulleval = sh.cnt.n_fulleval;
+        F.n_blockevals = sh.cnt.n_blockevals; F.t_mpA = sh.cnt.t_mpA; F.t_mpB = sh.cnt.t_mpB;
 #ifdef FC_SERIAL_PROFILE
         for (int k = 0; k < 8; k++) F.dbg[k] = sh.tk_ph[k];
 #endif

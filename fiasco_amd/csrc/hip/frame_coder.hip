@@ -113,7 +113,7 @@ struct SFrame {
     Range rg, lrange, rrange, child[2];
     Pool  pool0, pool_lc;
     float max_costs, lincomb, subdiv, ret, price;
-    int   label, states, phase, leaf;
+    int   label, states, phase, leaf, coop;
     int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
 };
 
@@ -873,6 +873,30 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
 }
 
+/* the same snapshots taken by the whole workgroup around a linear-combination search
+ * (codec/subdivide.c:188-237): before it, models -> slot 0 (+ tree model); after it, models ->
+ * slot 1 and slot 0 -> models.  One 16-byte element per lane. */
+__device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, int ML)
+{
+    const int tid = threadIdx.x;
+    if (tid < sh.n16) sh.snap_pool[(depth * 2 + 0) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
+    else if (tid >= 64 && tid < 64 + ML)
+        ((uint4 *) (sh.snap_tm + depth * 4 * ML))[tid - 64] = ((const uint4 *) sh.tm)[tid - 64];
+    else if (tid == 128) fr.pool0 = sh.pool;
+}
+
+__device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
+{
+    const int tid = threadIdx.x;
+    if (tid < sh.n16) {
+        sh.snap_pool[(depth * 2 + 1) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
+        ((uint4 *) &sh.cb)[tid] = sh.snap_pool[(depth * 2 + 0) * sh.n16 + tid];
+    } else if (tid == 128) {
+        fr.pool_lc = sh.pool;
+        sh.pool = fr.pool0;
+    }
+}
+
 #include "mp_device.inc"
 
 /* ------------------------------------------------------------------ serial state machine */
@@ -1089,7 +1113,10 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
              * touched without children -- the reference's duplicate/restore pairs
              * (codec/subdivide.c:188-237,404-468) are no-ops for it. */
             fr.leaf = rg.level <= sh.lc_min && rg.level <= F.lc_max;
-            if (!fr.leaf) {
+            /* the snapshots around a linear-combination search are taken by all lanes inside
+             * OP_APPROX (snap_coop_*), not by this one */
+            fr.coop = !fr.leaf && rg.level <= F.lc_max;
+            if (!fr.leaf && !fr.coop) {
                 fr.pool0 = sh.pool;
                 snap_save(F, sh, sh.sp, 0);
                 tm_save(sh, sh.sp, ML);
@@ -1117,10 +1144,12 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.phase = PH_DECIDE;
                 break;
             }
-            fr.pool_lc = sh.pool;
-            snap_save(F, sh, sh.sp, 1);
-            sh.pool = fr.pool0;
-            snap_load(F, sh, sh.sp, 0);
+            if (!fr.coop) {
+                fr.pool_lc = sh.pool;
+                snap_save(F, sh, sh.sp, 1);
+                sh.pool = fr.pool0;
+                snap_load(F, sh, sh.sp, 0);
+            }
             if (rg.level > sh.lc_min) {
                 Range z;
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;

@@ -193,7 +193,7 @@ struct Sh {
                            n_fulleval, n_blockevals, t_mpA, t_mpB;
     } cnt;                         /* DevFrame counters of the same names */
 #ifdef FC_SERIAL_PROFILE
-    unsigned long long tk_ph[8], ph_t0;
+    unsigned long long tk_ph[8], ph_t0, tk_init[2];
     int      ph_prev;
 #endif
     /* colour frames (codec/coder.c:775-800): band being coded, its dynamic minimum block
@@ -582,11 +582,19 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
         float v[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) v[k] = F.imgT[(size_t) k * P + s];
-        for (int a = 0; a < F.NA; a++) {
-            float ip = 0;
+        /* two addresses per step: packed fp32 multiply and add (v_pk_mul_f32 / v_pk_add_f32,
+         * each half rounded like the scalar op; no fused multiply-add), pixels read in pairs */
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        for (int a = 0; a < F.NA; a += 2) {
+            f2 ip = { 0.0f, 0.0f };
 #pragma unroll
-            for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * v[k];
-            F.d5[(size_t) a * P + s] = ip;
+            for (int k = 0; k < 32; k++) {
+                f2 px = { sh.pixels[a * 32 + k], sh.pixels[a * 32 + 32 + k] };
+                f2 vv = { v[k], v[k] };
+                ip = ip + px * vv;
+            }
+            F.d5[(size_t) a * P + s] = ip.x;
+            F.d5[(size_t) (a + 1) * P + s] = ip.y;
         }
 #if FC_VARIANT_BIG
         if (F.gl0 < F.images_level) {
@@ -636,9 +644,18 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
         }
         F.norms[slot] = nrm;
     }
+#ifdef FC_SERIAL_PROFILE
+    unsigned long long tp0 = wall_clock64();
+#endif
     op_d5(F, sh, 0, table_states(sh));
     __syncthreads();
+#ifdef FC_SERIAL_PROFILE
+    if (tid == 0) { unsigned long long t = wall_clock64(); sh.tk_init[0] += t - tp0; tp0 = t; }
+#endif
     op_ipis(F, sh, 0, 0, level, 0);
+#ifdef FC_SERIAL_PROFILE
+    if (tid == 0) sh.tk_init[1] += wall_clock64() - tp0;
+#endif
     if (tid == 0) {
         sh.cnt.bytes_img += (unsigned long long) table_states(sh) * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
         sh.cnt.n_blocks++;
@@ -1406,7 +1423,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
     unsigned long long *tk = sh.tk;
     if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;
 #ifdef FC_SERIAL_PROFILE
-    if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; }
+    if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; }
 #endif
     unsigned long long t_begin = wall_clock64();
     /* everything below is inlined into this one loop (a single call site per op keeps the
@@ -1449,6 +1466,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         F.n_blockevals = sh.cnt.n_blockevals; F.t_mpA = sh.cnt.t_mpA; F.t_mpB = sh.cnt.t_mpB;
 #ifdef FC_SERIAL_PROFILE
         for (int k = 0; k < 8; k++) F.dbg[k] = sh.tk_ph[k];
+        F.dbg[0] = sh.tk_init[0]; F.dbg[7] = sh.tk_init[1];      /* d5 / ipis of init_range */
 #endif
     }
     if (tid == 0) {

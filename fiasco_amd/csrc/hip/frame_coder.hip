@@ -202,7 +202,8 @@ struct Sh {
     short    dl[64];               /* candidate list of a chroma call: pool + luminance state */
     unsigned long long red[B / 64];
     /* term lists of the state being appended (uniform for the whole workgroup) */
-    int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2];
+    int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2], gs_raw_idx[2][MAXED + 1];
+    float    gs_raw_w[2][MAXED + 1];
     float    gs_w[2][MAXED + 1];
     int      states;               /* wfa->states */
     int      flim;                 /* Gram tables: states below it have mirrored entries */
@@ -666,13 +667,44 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
 __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
+    /* term lists of the new state s (slot 0 = tree child with weight 1 if any, then the
+     * edges): twelve lanes read one row slot each (one memory round trip instead of a chain of
+     * dependent ones), two lanes compact them into LDS; uniform for the whole workgroup */
+    if (tid < 12) {
+        const int l = tid / 6, e = tid % 6;
+        sh.gs_raw_idx[l][e] = e == 0 ? (int) TREE(F, s, l) : (int) INTO(F, s, l, e - 1);
+        sh.gs_raw_w[l][e] = e == 0 ? 1.0f : WEIGHT(F, s, l, e - 1);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const int l = tid;
+        int m = 0;
+        sh.gs_c[l] = sh.gs_raw_idx[l][0] != RANGE_;
+        if (sh.gs_c[l]) { sh.gs_idx[l][0] = sh.gs_raw_idx[l][0]; sh.gs_w[l][0] = 1.0f; m = 1; }
+        for (int e = 1; e <= MAXED && sh.gs_raw_idx[l][e] != NOEDGE; e++) {
+            sh.gs_idx[l][m] = sh.gs_raw_idx[l][e]; sh.gs_w[l][m] = sh.gs_raw_w[l][e]; m++;
+        }
+        sh.gs_n[l] = m;
+        for (; m <= MAXED; m++) { sh.gs_idx[l][m] = 0; sh.gs_w[l][m] = 0.0f; }   /* valid dummies */
+    }
+    __syncthreads();
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
-     * depends on level l-1 of OTHER states only */
+     * depends on level l-1 of OTHER states only (codec/control.c:205-258) */
     if (tid == B - 1) F.img[(size_t) s * F.NI] = F.final_d[s];
     for (int i = tid; i < F.NI - 1; i += B) {
         int l = 31 - __clz(i + 2);                      /* offset 2^l - 1 + pos = i + 1 */
         int pos = i + 1 - ((1 << l) - 1);
-        float v = image_elem(F, s, l, pos);
+        const int half = 1 << (l - 1), label = pos >= half;
+        const int off = half - 1 + (pos - label * half);
+        const int n = sh.gs_n[label];
+        float t[MAXED + 1];
+#pragma unroll
+        for (int a = 0; a <= MAXED; a++)                /* all term images in flight */
+            t[a] = F.img[(size_t) sh.gs_idx[label][a] * F.NI + off];      /* dead slots: state 0 */
+        float v = 0;
+#pragma unroll
+        for (int a = 0; a <= MAXED; a++)
+            if (a < n) v = (a == 0 && sh.gs_c[label]) ? t[0] : v + t[a] * sh.gs_w[label][a];
         F.img[(size_t) s * F.NI + i + 1] = v;
         if (l == il) F.imgT[(size_t) pos * P + s] = v;
 #if FC_VARIANT_BIG
@@ -682,15 +714,6 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
     __syncthreads();
     /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
     {
-        /* term lists (tree child weight 1 first, then the edges) of the new state s: uniform */
-        if (tid < 2) {          /* lists of s into LDS: slot 0 = tree child (if any), then edges */
-            int l = tid, k = TREE(F, s, l), m = 0;
-            sh.gs_c[l] = k != RANGE_;
-            if (k != RANGE_) { sh.gs_idx[l][m] = k; sh.gs_w[l][m] = 1.0f; m++; }
-            for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++) { sh.gs_idx[l][m] = d; sh.gs_w[l][m] = WEIGHT(F, s, l, e); m++; }
-            sh.gs_n[l] = m;
-        }
-        __syncthreads();
         const int flim = __builtin_amdgcn_readfirstlane(sh.flim);
         const int Pu = __builtin_amdgcn_readfirstlane(P);
         s = __builtin_amdgcn_readfirstlane(s);
@@ -698,9 +721,19 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         GLOBAL_AS float *const diag = uniform_ptr(F.diag);
         AutoTabs T;
         auto_tabs(F, T);
+        /* level-images_level image of s (the same for every lane): 32 loads in flight once;
+         * per t the other 32.  A `for (k < 1 << images_level)` loop is not unrolled by the
+         * compiler and would wait for every single load. */
+        GLOBAL_AS const float *imgT = uniform_ptr((const float *) F.imgT);
+        float vs[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) vs[k] = ldg(imgT, (unsigned) (k * Pu + s));
         for (int t = tid; t <= s; t += B) {
             EdgeRows rows;
             load_edge_rows(T, t, rows);
+            float vt[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) vt[k] = ldg(imgT, (unsigned) (k * Pu + t));
             if (!rows.dt) continue;
             /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
              * once and reused by every table level */
@@ -726,14 +759,21 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             int q1 = 1;
 #if FC_VARIANT_BIG
             if (F.gl0 < il) {                      /* levels <= images_level: direct dots */
-                float v4 = gram_dot4(F, s, t);
+                GLOBAL_AS const float *imgT4 = uniform_ptr((const float *) F.imgT4);
+                float a4[16], b4[16], v4 = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) { a4[k] = ldg(imgT4, (unsigned) (k * Pu + s)); b4[k] = ldg(imgT4, (unsigned) (k * Pu + t)); }
+#pragma unroll
+                for (int k = 0; k < 16; k++) v4 += a4[k] * b4[k];
                 stg(gram, (unsigned) (s * Pu + t), v4);
                 if (s == t) stg(diag, (unsigned) s, v4);
                 q1 = 2;
             }
 #endif
             {
-                float v0 = gram_dot(F, s, t);
+                float v0 = 0;                         /* codec/ip.c:297-323, sequential */
+#pragma unroll
+                for (int k = 0; k < 32; k++) v0 += vs[k] * vt[k];
                 stg(gram + (size_t) (q1 - 1) * Pu * Pu, (unsigned) (s * Pu + t), v0);
                 if (s == t) stg(diag, (unsigned) ((q1 - 1) * Pu + s), v0);
             }
@@ -744,11 +784,10 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                  * is used; dead term slots of t read a valid dummy entry (no per-lane branch). */
                 GLOBAL_AS const float *G = gram + (size_t) (q - 1) * Pu * Pu;
                 float ip = 0;
+                float g[2][MAXED + 1][MAXED + 1];
 #pragma unroll
-                for (int l = 0; l < 2; l++) {
+                for (int l = 0; l < 2; l++) {                      /* gathers of both labels */
                     const int na = __builtin_amdgcn_readfirstlane(sh.gs_n[l]);
-                    const int ca = __builtin_amdgcn_readfirstlane(sh.gs_c[l]);
-                    float g[MAXED + 1][MAXED + 1];
 #pragma unroll
                     for (int a = 0; a <= MAXED; a++) {
                         if (a >= na) break;                            /* uniform */
@@ -757,17 +796,22 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                         for (int b = 0; b <= MAXED; b++) {
                             const int bb = i2[l][b];
                             const bool mirror = bb > A && bb >= flim;     /* gram_load() */
-                            g[a][b] = ldg(G, (unsigned) (mirror ? bb * Pu + A : A * Pu + bb));
+                            g[l][a][b] = ldg(G, (unsigned) (mirror ? bb * Pu + A : A * Pu + bb));
                         }
                     }
+                }
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                    const int na = __builtin_amdgcn_readfirstlane(sh.gs_n[l]);
+                    const int ca = __builtin_amdgcn_readfirstlane(sh.gs_c[l]);
 #pragma unroll
                     for (int a = 0; a <= MAXED; a++) {
                         if (a >= na) break;
                         float sum = 0;
-                        if (m2[l] & 1u) sum = g[a][0];
+                        if (m2[l] & 1u) sum = g[l][a][0];
 #pragma unroll
                         for (int b = 1; b <= MAXED; b++)
-                            if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[a][b];
+                            if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[l][a][b];
                         if (a == 0 && ca) ip += sum;
                         else ip += sh.gs_w[l][a] * sum;
                     }
@@ -778,15 +822,21 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         }
     }
     for (int a = tid; a < F.NA; a += B) {
-        float ip = 0;
-        for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * F.imgT[(size_t) k * P + s];
+        float vs[32], ip = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) vs[k] = F.imgT[(size_t) k * P + s];
+#pragma unroll
+        for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * vs[k];
         F.d5[(size_t) a * P + s] = ip;
     }
 #if FC_VARIANT_BIG
     if (F.gl0 < il)
         for (int a = tid; a < 2 * F.NA; a += B) {
-            float ip = 0;
-            for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * F.imgT4[(size_t) k * P + s];
+            float v4[16], ip = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) v4[k] = F.imgT4[(size_t) k * P + s];
+#pragma unroll
+            for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v4[k];
             F.d4[(size_t) a * P + s] = ip;
         }
 #endif

@@ -193,7 +193,7 @@ struct Sh {
                            n_fulleval, n_blockevals, t_mpA, t_mpB;
     } cnt;                         /* DevFrame counters of the same names */
 #ifdef FC_SERIAL_PROFILE
-    unsigned long long tk_ph[8], ph_t0, tk_init[2];
+    unsigned long long tk_ph[8], ph_t0, tk_init[2], tk_apx[4];
     int      ph_prev;
 #endif
     /* colour frames (codec/coder.c:775-800): band being coded, its dynamic minimum block
@@ -618,16 +618,31 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
     const int16_t *plane = F.pix16 + (size_t) sh.band * F.plane;
-    for (int i = tid; i < npx; i += B) {
-        unsigned xo = 0, yo = 0;
-        for (int b = 0; b < 13; b++) {
-            yo |= ((i >> (2 * b)) & 1u) << b;         /* even bits: rows (mask 0x555555)   */
-            xo |= ((i >> (2 * b + 1)) & 1u) << b;     /* odd bits: columns (mask 0xaaaaaa) */
+    {   /* all pixel loads of the lane in flight: unconditional loads at clamped coordinates,
+         * the outside of the image is zeroed afterwards (codec/subdivide.c:504-541) */
+        constexpr int NIT = FC_PIXELS / B;
+        const int width = F.width, height = F.height;
+        int raw[NIT];
+        bool inside[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * B;
+            unsigned xo = 0, yo = 0;
+#pragma unroll
+            for (int b = 0; b < 13; b++) {
+                yo |= ((i >> (2 * b)) & 1u) << b;         /* even bits: rows (mask 0x555555)   */
+                xo |= ((i >> (2 * b + 1)) & 1u) << b;     /* odd bits: columns (mask 0xaaaaaa) */
+            }
+            const int x = x0 + (int) xo, y = y0 + (int) yo;
+            inside[it] = i < npx && y < height && x < width;
+            const int xc = x < width ? x : width - 1, yc = y < height ? y : height - 1;
+            raw[it] = plane[(size_t) yc * width + xc];
         }
-        int x = x0 + (int) xo, y = y0 + (int) yo;
-        float v = 0;
-        if (y < F.height && x < F.width) v = (float) (plane[(size_t) y * F.width + x] / 16);
-        sh.pixels[i] = v;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * B;
+            if (i < npx) sh.pixels[i] = inside[it] ? (float) (raw[it] / 16) : 0.0f;
+        }
     }
     __syncthreads();
     /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
@@ -1473,7 +1488,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
     unsigned long long *tk = sh.tk;
     if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;
 #ifdef FC_SERIAL_PROFILE
-    if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; }
+    if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; for (int k = 0; k < 4; k++) sh.tk_apx[k] = 0; }
 #endif
     unsigned long long t_begin = wall_clock64();
     /* everything below is inlined into this one loop (a single call site per op keeps the
@@ -1517,6 +1532,8 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
 #ifdef FC_SERIAL_PROFILE
         for (int k = 0; k < 8; k++) F.dbg[k] = sh.tk_ph[k];
         F.dbg[0] = sh.tk_init[0]; F.dbg[7] = sh.tk_init[1];      /* d5 / ipis of init_range */
+        /* OP_APPROX: tables, init, steps, finalize (replace the CHILD* phase slots) */
+        F.dbg[3] = sh.tk_apx[0]; F.dbg[4] = sh.tk_apx[1]; F.dbg[5] = sh.tk_apx[2]; F.dbg[2] = sh.tk_apx[3];
 #endif
     }
     if (tid == 0) {

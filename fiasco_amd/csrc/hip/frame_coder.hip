@@ -187,6 +187,7 @@ struct Sh {
 #endif
     float    blockmin[NBLOCKMIN];
     float    pixels[FC_PIXELS];
+    float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
     unsigned long long tk[8];      /* ticks per op (lane 0) */
     struct {
         unsigned long long bytes_mp, bytes_img, bytes_gram, n_mp, n_steps, n_blocks, n_appends,
@@ -205,6 +206,9 @@ struct Sh {
     int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2], gs_raw_idx[2][MAXED + 1];
     float    gs_raw_w[2][MAXED + 1];
     float    gs_w[2][MAXED + 1];
+    /* parameters the serial lane reads per range, copied from the frame descriptor once (a
+     * field of the descriptor is a global-memory round trip in the out-of-line search code) */
+    struct { int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease; } par;
     int      states;               /* wfa->states */
     int      flim;                 /* Gram tables: states below it have mirrored entries */
     int      failed;
@@ -658,7 +662,7 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
             nrm += p0 * p0; nrm += p1 * p1; nrm += p2 * p2; nrm += p3 * p3;
             nrm += p4 * p4; nrm += p5 * p5; nrm += p6 * p6; nrm += p7 * p7;
         }
-        F.norms[slot] = nrm;
+        sh.norms[slot] = nrm;              /* LDS: read by lane 0 at the start of every search */
     }
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tp0 = wall_clock64();
@@ -1155,7 +1159,7 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 /* advance the partition search until a data-parallel operation is required */
 __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 {
-    const int ML = F.ML;
+    const int ML = sh.par.ML;
     for (;;) {
         if (sh.sp < 0) {
             if (!band_advance(F, sh)) { sh.op = OP_DONE; return; }
@@ -1176,11 +1180,11 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             rg.tree = RANGE_;
             fr.ret = MAXCOSTS;
             if (sh.failed || rg.level < 3) { fr.ret = MAXCOSTS; goto pop; }
-            if (rg.x >= F.width || rg.y >= F.height) { fr.ret = 0; goto pop; }
-            fr.price = F.price;
-            if (sh.band) fr.price *= F.chroma_decrease;
+            if (rg.x >= sh.par.width || rg.y >= sh.par.height) { fr.ret = 0; goto pop; }
+            fr.price = sh.par.price;
+            if (sh.band) fr.price *= sh.par.chroma_decrease;
             fr.phase = PH_AFTER_INIT;
-            if (rg.level == F.lc_max) {
+            if (rg.level == sh.par.lc_max) {
                 rg.address = rg.image = 0;
                 sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
                 return;
@@ -1194,10 +1198,10 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
              * accepted one is exactly the state to continue from, and the tree model is not
              * touched without children -- the reference's duplicate/restore pairs
              * (codec/subdivide.c:188-237,404-468) are no-ops for it. */
-            fr.leaf = rg.level <= sh.lc_min && rg.level <= F.lc_max;
+            fr.leaf = rg.level <= sh.lc_min && rg.level <= sh.par.lc_max;
             /* the snapshots around a linear-combination search are taken by all lanes inside
              * OP_APPROX (snap_coop_*), not by this one */
-            fr.coop = !fr.leaf && rg.level <= F.lc_max;
+            fr.coop = !fr.leaf && rg.level <= sh.par.lc_max;
             if (!fr.leaf && !fr.coop) {
                 fr.pool0 = sh.pool;
                 snap_save(F, sh, sh.sp, 0);
@@ -1207,7 +1211,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             for (int l = 0; l < 2; l++)                 /* codec/subdivide.c:167-173 */
                 fr.ny[l] = (sh.band && fr.y_state != RANGE_) ? (int) TREE(F, fr.y_state, l) : RANGE_;
             fr.phase = PH_AFTER_LC;
-            if (rg.level <= F.lc_max) {
+            if (rg.level <= sh.par.lc_max) {
                 fr.lrange = rg;
                 fr.lrange.tree = RANGE_;
                 fr.lrange.tree_bits = tree_bits_dev(sh, ML, 0, rg.level, 0);
@@ -1262,7 +1266,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             ch.x = (rr.level & 1) ? rr.x : rr.x + label * (int) width_of_level(rr.level - 1);
             ch.y = (rr.level & 1) ? rr.y + label * (int) height_of_level(rr.level - 1) : rr.y;
             fr.phase = PH_CHILD2;
-            if (label && rr.level <= F.lc_max && sh.states > fr.states && !sh.band) {
+            if (label && rr.level <= sh.par.lc_max && sh.states > fr.states && !sh.band) {
                 sh.op = OP_IPIS_INCR; sh.a0 = ch.image; sh.a1 = ch.address; sh.a2 = ch.level;
                 sh.a3 = fr.states;
                 return;
@@ -1331,9 +1335,9 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.ret = fr.lincomb;
                 goto pop;
             } else {
-                int aux = sh.band > 0 || rg.x + (int) width_of_level(rg.level) > F.width
-                          || rg.y + (int) height_of_level(rg.level) > F.height;
-                if (sh.states >= (sh.band ? F.PA : F.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+                int aux = sh.band > 0 || rg.x + (int) width_of_level(rg.level) > sh.par.width
+                          || rg.y + (int) height_of_level(rg.level) > sh.par.height;
+                if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
                 store_new_state(F, sh, fr, aux);
                 fr.phase = PH_AFTER_APPEND;
                 if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return; }
@@ -1342,7 +1346,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         }
         case PH_AFTER_APPEND: {
             sh.states++;
-            if (sh.states >= F.limit_states) sh.failed = FC_ERR_STATES;
+            if (sh.states >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
             fr.rg = fr.rrange;
             fr.ret = fr.subdiv;
             goto pop;
@@ -1480,6 +1484,9 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
         sh.flim = 0;
+        sh.par.lc_max = F.lc_max; sh.par.width = F.width; sh.par.height = F.height;
+        sh.par.limit_states = F.limit_states; sh.par.PA = F.PA; sh.par.P = F.P; sh.par.ML = F.ML;
+        sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
         sh.band = 0; sh.lc_min = F.lc_min; sh.after_chroma = 0; sh.ystates = 0;
         push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */

@@ -126,7 +126,7 @@ struct MPState {
     float norm_ov[MAXED + 1], ipio[MAXED + 1];
     short psorted[MAXED + 1];
     int   np;
-    float wb_dc, wb_nd, norm, ab, price, max_costs;
+    float wb_dc, wb_nd, norm, ab, price;
     int   y_state, ypos;         /* usable co-located luminance state / its list position, or -1 */
 #if FC_VARIANT_BIG
     const float *numrow;         /* <range, state> row of the call: ipis slot, d5 or d4 address */
@@ -136,9 +136,6 @@ struct MPState {
     float s1_pre[MAXED], s1_sfx[MAXED], s1_z0, s1_zy;
     int   s1_last[MAXED], s1_k[MAXED], s1_thr[MAXED];
     unsigned s1_cd, s1_has;
-    /* best candidate of the running step */
-    float b_cost, b_mbits, b_wbits, b_err, b_f[MAXED];
-    int   b_index;
 };
 
 /* aac model (coeff.c:190-208): totals first, then the counts, one 16-byte aligned block so
@@ -238,25 +235,6 @@ __device__ int rtob_dev(float f, int mant, float range)
     return (int) (((m & ((1u << mant) - 1)) << 1) | (unsigned) sign);
 }
 
-/* lib/rpf.c:114-169 */
-__device__ float btor_dev(int b, int mant, float range)
-{
-    if (b == -1) return 0.0f;
-    int sign = b & 1;
-    unsigned m = ((unsigned) b & ((1u << (mant + 1)) - 1)) >> 1;
-    m <<= (23 - mant);
-    float v;
-    if (m == 0)
-        v = sign ? -1.0f : 1.0f;
-    else {
-        int e = 0;
-        while (!(m & (1u << 22))) { e--; m <<= 1; }
-        m <<= 1;
-        v = __uint_as_float(((unsigned) sign << 31) | ((unsigned) (e + 126) << 23) | (m & 0x7fffffu));
-    }
-    return v * range;
-}
-
 /* lib/misc.c:223-244 */
 __device__ __forceinline__ unsigned bits_bin_code(unsigned value, unsigned maxval)
 {
@@ -271,22 +249,6 @@ __device__ __forceinline__ int qac_shift(int index)
     int n = 1, start = 0;
     while (index >= start + (1 << n)) { start += 1 << n; n++; }
     return n;
-}
-
-/* rle_bits (domain-pool.c:737-793) for an ascending list of non-y positions */
-__device__ float pool_bits_sorted(const short *sorted, int nn, const Sh &sh)
-{
-    float bits = sh.Ltab[nn];
-    bits += (nn && sorted[0] == 0) ? sh.Q1 : sh.Q0;
-    unsigned last = 1, N = (unsigned) sh.mp.N;
-    for (int e = 0; e < nn; e++) {
-        int into = sorted[e];
-        if (into && (N - 1 - last)) {
-            bits += (float) bits_bin_code((unsigned) into - last, N - 1 - last);
-            last = (unsigned) into + 1;
-        }
-    }
-    return bits;
 }
 
 /* ------------------------------------------------------------------ table access */

@@ -178,3 +178,16 @@ def test_submit_collect_on_oracle_seam(oracle, inputs):
     assert b.collect(resubmit=True) == ref
     assert b.collect() == ref
     b.free()
+
+
+def test_stage1_pricing_restructuring(tmp_path):
+    """The device prices the run-length part of a candidate from per-step uniform parts
+    (mp_device.inc, StepCtx); tests/stage1_pricing_check.c replays that algebra on the CPU
+    against the plain walk over the merged position list -- every float must be identical."""
+    import subprocess
+    exe = str(tmp_path / "s1check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage1_pricing_check.c")
+    subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-o", exe, src])
+    out = subprocess.run([exe, "400000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert " 0 mismatches" in out.stdout

@@ -613,7 +613,7 @@ static void complete_wave(Staged *S)
             const char *msg = "device coder failed";
             if (st == FC_ERR_STATES || st == FC_ERR_CAPACITY) msg = "Maximum number of states reached!";
             else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
-            else if (st == FC_ERR_INTERNAL) msg = "device coder: recursion depth exceeded";
+            else if (st == FC_ERR_INTERNAL) msg = "device coder: frame exceeds a built-in capacity (recursion depth, snapshot stack or 16384 states)";
             snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
         }
     }

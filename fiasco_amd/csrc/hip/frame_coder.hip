@@ -1436,7 +1436,9 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         /* aac model, all-ones (coeff.c:297-310) */
         sh.n16 = (32 + 2 * F.coeff_size + 15) / 16;
         if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16
-            || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16)
+            || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16
+            || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
+            || F.level - F.lc_min + 2 > FC_MAXDEPTH)
             sh.failed = FC_ERR_INTERNAL;
         for (int i = 0; i < FC_MAXCOEFF; i++) sh.cb.cnt[i] = 0;
         for (int i = 0; i < 16; i++) sh.cb.tot[i] = 0;

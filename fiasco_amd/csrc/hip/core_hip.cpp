@@ -156,7 +156,15 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         return 0;
     }
     if (cp->lc_max_level > 12) { snprintf(why, n, "max block level > 12 is not supported by the device coder"); return 0; }
-    if (cp->max_elements > 5) { snprintf(why, n, "more than 5 vectors per block are not supported"); return 0; }
+    if (cp->max_elements > 5) { snprintf(why, n, "more than 5 vectors per block are not supported by the device coder"); return 0; }
+    {
+        unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
+        if ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF) {
+            snprintf(why, n, "coefficient model too large for the device coder "
+                             "(block levels x mantissa symbols > %d)", FC_MAXCOEFF);
+            return 0;
+        }
+    }
     if (cp->rpf.mantissa_bits > 5 || cp->dc_rpf.mantissa_bits > 5) {
         snprintf(why, n, "RPF mantissa > 5 bits is not supported by the device coder yet");
         return 0;
@@ -174,7 +182,7 @@ struct FrameSlot {
     int      P = 0, PA = 0;
     Layout   L;
     DevFrame F;
-    bool     staged = false, done = false, big = false;
+    bool     staged = false, done = false, big = false, rejected = false;
 };
 
 struct Staged {
@@ -280,8 +288,10 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     }
     fill_frame(fs, job);
     if (fs.F.coeff_size > FC_MAXCOEFF || fs.F.dcs > FC_MAXSYM || fs.F.sy > FC_MAXSYM || fs.F.ML > 26) {
-        snprintf(job->errmsg, sizeof job->errmsg, "coefficient model too large for the device coder");
+        snprintf(job->errmsg, sizeof job->errmsg,
+                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", FC_MAXCOEFF);
         slab_release(fs.base, fs.bytes); fs.base = nullptr;
+        fs.done = true; fs.rejected = true;      /* permanent: not a matter of free HBM */
         return 0;
     }
     for (int b = 0; b < bands; b++)
@@ -356,6 +366,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         size_t free_b = 0, total_b = 0;
         (void) hipMemGetInfo(&free_b, &total_b);
         if (!stage_slot(S, S->slots[k])) {
+            if (S->slots[k].rejected) continue;   /* outside the device scope: message recorded */
             if (k == 0) continue;          /* does not fit even alone: error already recorded */
             S->jobs[S->slots[k].job].errmsg[0] = 0;   /* later wave */
             break;
@@ -674,7 +685,7 @@ extern "C" int fa_core_finish2(void *h, int resubmit)
         for (size_t k = 0; k < S->slots.size(); k++) {
             FrameSlot &fs = S->slots[k];
             if (fs.staged || fs.done || S->jobs[fs.job].errmsg[0]) continue;
-            if (stage_slot(S, fs)) any = true; else break;
+            if (stage_slot(S, fs)) any = true; else if (!fs.rejected) break;
         }
         if (!any) break;
     }

@@ -980,8 +980,16 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
         int aux = band > FA_Y
                   || rg->x + fa_width_of_level(rg->level) > c->im->width
                   || rg->y + fa_height_of_level(rg->level) > c->im->height;
-        init_new_state(c, aux, &rrange, child, new_y_state);
-        *rg = rrange;
+        /* the reference leaves through longjmp at the first "Maximum number of states
+         * reached!" (codec/control.c:129-130); this restatement unwinds normally, so nothing
+         * may be appended once the frame has failed */
+        if (c->failed || w->states >= c->cp->limit_states) {
+            fail(c, "Maximum number of states reached!");
+            subdivide_costs = FA_MAXCOSTS;
+        } else {
+            init_new_state(c, aux, &rrange, child, new_y_state);
+            *rg = rrange;
+        }
     }
     free(coeff0); free(ct0); free(coeff_lc); free(ct_lc); free(tm0);
     return subdivide_costs;

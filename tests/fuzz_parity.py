@@ -1,0 +1,107 @@
+"""Developer tool (GPU box): differential fuzzing of the device coder against the CPU oracle.
+
+Random gray/colour images of random (even) sizes, qualities and option sets -- everything the
+device scope covers: block-level windows 4..12, 1..5 vectors, second-domain retry, dictionary
+sizes, RPF mantissas/ranges, chroma options -- encoded by both libraries through
+fiasco_amd_encode_batch; any byte difference is reported with the seed that reproduces it.
+
+usage: fuzz_parity.py [rounds] [frames_per_round] [seed0]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fiasco_amd
+import synth
+
+
+def random_image(rng, colour):
+    w = int(rng.integers(16, 200)) * 2
+    h = int(rng.integers(16, 160)) * 2
+    kind = int(rng.integers(0, 5))
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    def plane():
+        if kind == 0:
+            a = 128 + 60 * np.sin(x / rng.uniform(5, 40)) * np.cos(y / rng.uniform(5, 40)) + rng.normal(0, rng.uniform(0, 12), (h, w))
+        elif kind == 1:
+            a = rng.integers(0, 256, (h, w)).astype(np.float64)
+        elif kind == 2:
+            a = np.full((h, w), float(rng.integers(0, 256))) + rng.normal(0, 1.5, (h, w))
+        elif kind == 3:
+            a = 255.0 * (((x // rng.integers(2, 40)) + (y // rng.integers(2, 40))) % 2)
+        else:
+            a = 128 + 100 * np.tanh((x - w / 2) / rng.uniform(3, 60)) + 20 * np.sin(y / 7.0)
+        return np.clip(a, 0, 255).astype(np.uint8)
+    if colour:
+        return synth.ppm_bytes(np.stack([plane(), plane(), plane()], -1))
+    return synth.pgm_bytes(plane())
+
+
+def random_options(rng, lib=None):
+    lo = int(rng.integers(4, 9))
+    hi = int(rng.integers(max(lo, 6), 13))
+    el = int(rng.integers(1, 6))
+    lvl = int(rng.integers(0, 2))
+    dic = int(rng.choice([8, 40, 300, 10000]))
+    mant = int(rng.integers(2, 6)); dmant = int(rng.integers(2, 6))
+    rr = int(rng.integers(0, 4)); dr = int(rng.integers(0, 4))
+    cq = float(rng.choice([1.0, 2.0, 3.5])); cd = int(rng.choice([1, 5, 40, 63]))
+    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd)
+    return spec
+
+
+def apply(o, spec):
+    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd = spec
+    o.set_optimizations(lo, hi, el, dic, lvl)
+    o.set_quantization(mant, rr, dmant, dr)
+    o.set_chroma_quality(cq, cd)
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    gpu = fiasco_amd.library()
+    ora = fiasco_amd.Library(os.path.join(os.path.dirname(fiasco_amd.LIB_PATH), "..", "oracle", "liboracle_fiasco.so"))
+    gpu.set_verbosity(0); ora.set_verbosity(0)
+    bad = 0
+    refused = 0
+    n = 0
+    t0 = time.time()
+    for r in range(rounds):
+        rng = np.random.default_rng(seed0 + r)
+        spec = random_options(rng, gpu)
+        q = float(rng.choice([2.0, 8.0, 20.0, 45.0, 90.0]))
+        frames = [random_image(rng, bool(rng.integers(0, 3) == 0)) for _ in range(per)]
+        og, oo = gpu.cli_options(), ora.cli_options()
+        apply(og, spec); apply(oo, spec)
+        if r % 2:
+            os.environ["FIASCO_AMD_NO_WIDE"] = "1"
+        else:
+            os.environ.pop("FIASCO_AMD_NO_WIDE", None)
+        print("round seed %d spec %s q %s" % (seed0 + r, spec, q), flush=True)
+        got = gpu.encode_batch(frames, q, og)
+        gmsg = gpu.error_message()
+        exp = ora.encode_batch(frames, q, oo)
+        og.delete(); oo.delete()
+        for i, (g, e) in enumerate(zip(got, exp)):
+            n += 1
+            if g is None and e is not None and "device coder" in gmsg:
+                refused += 1                      # outside the device scope, said so
+                continue
+            if g != e:
+                bad += 1
+                print("MISMATCH seed %d frame %d spec %s q %s: device %s oracle %s (%s)"
+                      % (seed0 + r, i, spec, q, None if g is None else len(g), None if e is None else len(e),
+                         gmsg if g is None else ""), flush=True)
+    print("fuzz: %d frames in %d rounds, %d mismatches, %d refused by the device (with message), %.1f s"
+          % (n, rounds, bad, refused, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

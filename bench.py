@@ -93,17 +93,25 @@ def main():
     import torch.distributed as dist
     import synth
     import fiasco_amd
-    from fiasco_amd.sharding import gather_streams
+    from fiasco_amd.sharding import gather_streams, shard_indices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # developer check of the multi-rank path on a 1-GPU box: all ranks on GPU 0, gloo for the
+    # (tiny) collectives -- FIASCO_BENCH_SAME_GPU=1 torchrun --nproc-per-node 2 bench.py ...
+    same_gpu = os.environ.get("FIASCO_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if same_gpu else dev          # where the collectives' tensors live
 
     lib = fiasco_amd.library()
     lib.set_verbosity(0)
@@ -142,15 +150,17 @@ def main():
     batch.free()
     assert out is not None and all(o is not None for o in out), lib.error_message()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
     agg = torch.tensor([float(st.kernel_ms), float(st.bytes_mp + st.bytes_img + st.bytes_gram),
-                        float(st.launches), float(st.frames)], dtype=torch.float64, device=dev)
+                        float(st.launches), float(st.frames)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         # trivial gather of the per-rank streams over RCCL (outside the timed region)
-        local_streams = {rank * len(uniq) + i: out[i] for i in range(len(uniq))}
-        alls = gather_streams(local_streams, world * len(uniq), device=dev)
+        # global item r + i*W is distinct frame i of rank r (round-robin, sharding.shard_indices)
+        keys = shard_indices(world * len(uniq), rank, world)
+        local_streams = {k: out[i] for i, k in enumerate(keys)}
+        alls = gather_streams(local_streams, world * len(uniq), device=cdev)
         assert all(s and s[:7] == b"FIASCO\n" for s in alls)
     dt = float(t.item())
     kernel_ms, alg_bytes, launches, nframes = [float(x) for x in agg.tolist()]

@@ -20,8 +20,9 @@ import synth
 
 
 def random_image(rng, colour):
-    w = int(rng.integers(16, 200)) * 2
-    h = int(rng.integers(16, 160)) * 2
+    big = int(os.environ.get("FUZZ_BIG", "0"))          # FUZZ_BIG=1: sizes up to 1000 x 800
+    w = int(rng.integers(16, 500 if big else 200)) * 2
+    h = int(rng.integers(16, 400 if big else 160)) * 2
     kind = int(rng.integers(0, 5))
     y, x = np.mgrid[0:h, 0:w].astype(np.float64)
     def plane():

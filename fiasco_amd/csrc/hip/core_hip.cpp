@@ -33,7 +33,7 @@ extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t s
 static bool needs_big_variant(const fa_cparams *cp)
 {
     return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
-           || cp->second_domain_block;
+           || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search;
 }
 
 static fiasco_amd_stats g_stats;
@@ -98,7 +98,7 @@ extern "C" void fiasco_amd_release_memory(void)
 
 struct Layout {
     size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
-           final_d, level_of_state, domain_type, x, y, pool_states, pos, hits, pix16, total;
+           final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, pix16, total;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
@@ -131,6 +131,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(domain_type, (size_t) PA);
     CARVE(x, (size_t) 2 * PA * 2);
     CARVE(y, (size_t) 2 * PA * 2);
+    CARVE(ycol, (size_t) 2 * PA);
     CARVE(pool_states, (size_t) (P + 8) * 2);
     CARVE(pos, (size_t) (PA + 8) * 2);
     CARVE(hits, (size_t) (PA + 8) * 4);
@@ -149,10 +150,6 @@ static int device_supported(const fa_job *job, char *why, size_t n)
     }
     if (cp->images_level != 5 || cp->lc_min_level < 4) {
         snprintf(why, n, "device coder needs images_level 5 and min block level >= 4");
-        return 0;
-    }
-    if (cp->check_for_underflow || cp->check_for_overflow || cp->full_search) {
-        snprintf(why, n, "optimisation level > 1 (cfiasco -z 3) is not supported by the device coder");
         return 0;
     }
     if (cp->lc_max_level > 12) { snprintf(why, n, "max block level > 12 is not supported by the device coder"); return 0; }
@@ -229,6 +226,9 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.gl0 = (int) (cp->lc_min_level < cp->images_level ? cp->lc_min_level : cp->images_level);
     F.NL = (int) cp->lc_max_level - F.gl0 + 1;
     F.second_domain_block = cp->second_domain_block ? 1 : 0;
+    F.check_underflow = cp->check_for_underflow ? 1 : 0;
+    F.check_overflow = cp->check_for_overflow ? 1 : 0;
+    F.full_search = cp->full_search ? 1 : 0;
     F.NS = (int) fa_size_of_tree(cp->products_level);
     F.NA = 1 << (cp->lc_max_level - cp->images_level);
     F.NI = (int) fa_size_of_tree(cp->images_level);
@@ -262,6 +262,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.level_of_state = (uint8_t *) (base + L.level_of_state);
     F.domain_type = (uint8_t *) (base + L.domain_type);
     F.x = (uint16_t *) (base + L.x); F.y = (uint16_t *) (base + L.y);
+    F.ycol = (uint8_t *) (base + L.ycol);
     F.pool_states = (int16_t *) (base + L.pool_states);
     F.pos = (int16_t *) (base + L.pos);
     F.hits = (int *) (base + L.hits);
@@ -405,6 +406,8 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     const uint8_t *dt = (const uint8_t *) (host.data() + (L.domain_type - L.tree));
     const uint16_t *xs = (const uint16_t *) (host.data() + (L.x - L.tree));
     const uint16_t *ys = (const uint16_t *) (host.data() + (L.y - L.tree));
+    const uint8_t *ycol = (const uint8_t *) (host.data() + (L.ycol - L.tree));
+    for (unsigned s = 0; s < w->basis_states; s++) w->level_of_state[s] = 0xff;   /* codec/control.c:133-173 */
     fa_wfa_remove_states(w, w->basis_states);
     for (unsigned s = w->basis_states; s < ns; s++) {
         w->final_distribution[s] = fin[s];
@@ -416,7 +419,7 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
             w->x[s * 2 + l] = xs[(size_t) l * P + s];
             w->y[s * 2 + l] = ys[(size_t) l * P + s];
             w->y_state[s * 2 + l] = FA_RANGE;
-            w->y_column[s * 2 + l] = 0;
+            w->y_column[s * 2 + l] = F.color ? ycol[(size_t) l * P + s] : 0;
             w->prediction[s * 2 + l] = 0;
             for (int e = 0; e < 6; e++) {
                 FA_INTO(w, s, l, e) = into[(size_t) (l * 6 + e) * P + s];
@@ -454,8 +457,6 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
                 for (int l = 0; l < 2; l++) {
                     int ny = y != FA_RANGE ? FA_TREE(w, y, l) : FA_RANGE;
                     w->y_state[s * 2 + l] = (int16_t) ny;
-                    for (int e = 0; FA_INTO(w, s, l, e) != FA_NO_EDGE; e++)
-                        if (FA_INTO(w, s, l, e) == ny) w->y_column[s * 2 + l] = 1;
                     stack.push_back(std::make_pair((int) FA_TREE(w, s, l), ny));
                 }
             }

@@ -41,6 +41,7 @@ typedef struct DevFrame {
     int      lc_min, lc_max, images_level, max_elements;
     int      gl0;          /* lowest level with a Gram table: min(lc_min, images_level) */
     int      second_domain_block;   /* codec/approx.c:103-118 (cfiasco -z 2) */
+    int      check_underflow, check_overflow, full_search;   /* :119-206,420 (cfiasco -z 3) */
     int      level, width, height;
     int      pool_max, limit_states, ML;
     int      rpf_mant, dc_mant;
@@ -70,6 +71,7 @@ typedef struct DevFrame {
     float   *weight, *final_d;
     uint8_t *level_of_state, *domain_type;
     uint16_t *x, *y;
+    uint8_t *ycol;         /* [2][PA] y_column of wfa_t, kept per state ID across removals */
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     int     *hits;         /* [P] edge-target histogram for the chroma domain list */

@@ -130,7 +130,7 @@ struct MPState {
     int   y_state, ypos;         /* usable co-located luminance state / its list position, or -1 */
 #if FC_VARIANT_BIG
     const float *numrow;         /* <range, state> row of the call: ipis slot, d5 or d4 address */
-    int   excl;                  /* list position excluded from this run or -1 */
+    short excl[MAXED + 1];       /* list positions excluded from this run, NOEDGE terminated */
 #endif
     /* per-step uniform parts of the stage-1 position pricing (mp_device.inc, StepCtx) */
     float s1_pre[MAXED], s1_sfx[MAXED], s1_z0, s1_zy;
@@ -175,12 +175,13 @@ struct Sh {
     __attribute__((aligned(16))) unsigned tm[TM_WORDS];
     __attribute__((aligned(16))) unsigned snap_tm[SNAP_TM_WORDS];
     float    m0tab[12];
-    double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM];
+    double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM], lglv_m1;
     float    Ltab[MAXED + 1];
     float    Q0, Q1;
     MPState  mp;
 #if FC_VARIANT_BIG
-    MPState  mp_keep;              /* result of the first run (second_domain_block) */
+    MPState  mp_keep;              /* best result so far of a call with retries */
+    int      apx_stage, apx_it, apx_more;   /* retry plan of approximate_range (lane 0) */
 #endif
     float    blockmin[NBLOCKMIN];
     float    pixels[FC_PIXELS];
@@ -1040,6 +1041,15 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
         }
         for (int e = 0; e < ne; e++) { INTO(F, s, l, e) = si[e]; WEIGHT(F, s, l, e) = sw[e]; }
         INTO(F, s, l, ne) = NOEDGE;
+        /* y_column (codec/subdivide.c:560-567).  The flag stays with the state ID when the
+         * state is removed again (remove_states, codec/wfalib.c:283-309, does not clear it)
+         * and the join states of a colour frame never set theirs: they show what an earlier,
+         * removed state of the same ID left behind, and the stream writer reads it. */
+        if (F.color) {
+            int yc = 0;
+            for (int e = 0; ch.into[e] != NOEDGE; e++) if (ch.into[e] == fr.ny[l]) yc = 1;
+            F.ycol[l * F.PA + s] = (uint8_t) yc;
+        }
     }
     F.final_d[s] = final_distribution_dev(F, s);
     F.level_of_state[s] = (uint8_t) fr.rrange.level;
@@ -1455,6 +1465,8 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */
     }
+    if (F.color)                              /* calloc'ed in the reference (codec/wfa.h) */
+        for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = 0;
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
     if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;

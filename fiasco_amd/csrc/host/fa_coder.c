@@ -431,6 +431,28 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
  * threads */
 typedef struct { fiasco_amd_batch_t *b; unsigned char **outv; size_t *out_len; unsigned t, nt, good; } wr_task;
 
+/* developer aid: FIASCO_DUMP_WFA=<file> appends a text dump of every automaton handed to the
+ * writer (diff the dumps of two cores to find what the per-call traces cannot show) */
+static void dump_wfa(const fa_wfa *w)
+{
+    const char *path = getenv("FIASCO_DUMP_WFA");
+    FILE *f;
+    unsigned s, l, e;
+    if (!path || !(f = fopen(path, "a"))) return;
+    fprintf(f, "wfa states %u basis %u root %u\n", w->states, w->basis_states, w->root_state);
+    for (s = 0; s < w->states; s++) {
+        fprintf(f, "%u: fd %.9g lvl %u dt %u", s, w->final_distribution[s], w->level_of_state[s], w->domain_type[s]);
+        for (l = 0; l < 2; l++) {
+            fprintf(f, " | t %d xy %u,%u ys %d yc %u :", FA_TREE(w, s, l), w->x[s * 2 + l], w->y[s * 2 + l],
+                    w->y_state[s * 2 + l], w->y_column[s * 2 + l]);
+            for (e = 0; e < 6 && FA_INTO(w, s, l, e) != FA_NO_EDGE; e++)
+                fprintf(f, " %d*%.9g", FA_INTO(w, s, l, e), FA_WEIGHT(w, s, l, e));
+        }
+        fprintf(f, "\n");
+    }
+    fclose(f);
+}
+
 static void *wr_thread(void *arg)
 {
     wr_task *w = (wr_task *) arg;
@@ -439,6 +461,7 @@ static void *wr_thread(void *arg)
     for (i = w->t; i < b->n; i += w->nt) {
         fa_bitw out;
         if (!b->jobs[i].status) continue;
+        if (b->n == 1) dump_wfa(b->jobs[i].wfa);
         fa_bw_init(&out);
         if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, 0, b->normal_domains,
                            b->delta_domains, &out)) {

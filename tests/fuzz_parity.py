@@ -46,7 +46,7 @@ def random_options(rng, lib=None):
     lo = int(rng.integers(4, 9))
     hi = int(rng.integers(max(lo, 6), 13))
     el = int(rng.integers(1, 6))
-    lvl = int(rng.integers(0, 2))
+    lvl = int(rng.integers(0, 3))                       # 2: retries + full_search (cfiasco -z 3)
     dic = int(rng.choice([8, 40, 300, 10000]))
     mant = int(rng.integers(2, 6)); dmant = int(rng.integers(2, 6))
     rr = int(rng.integers(0, 4)); dr = int(rng.integers(0, 4))

@@ -28,4 +28,4 @@ for f in $names; do
   echo "$f: oracle $(stat -c %s gpurun_out/q/$f.or.fco) $(md5sum < gpurun_out/q/$f.or.fco | cut -c1-12)  device $(stat -c %s gpurun_out/q/$f.gpu.fco) $(md5sum < gpurun_out/q/$f.gpu.fco | cut -c1-12)"
   python3 tests/trace_diff.py gpurun_out/q/$f.or.trace gpurun_out/q/$f.gpu.trace
 done
-rm -f gpurun_out/q/*.trace gpurun_out/q/*.pnm
+[ -n "${KEEP_TRACE:-}" ] || rm -f gpurun_out/q/*.trace; rm -f gpurun_out/q/*.pnm

@@ -99,6 +99,40 @@ def main():
                 print("MISMATCH seed %d frame %d spec %s q %s: device %s oracle %s (%s)"
                       % (seed0 + r, i, spec, q, None if g is None else len(g), None if e is None else len(e),
                          gmsg if g is None else ""), flush=True)
+    # a few multi-frame streams through fiasco_coder() (all-I; colour streams carry the ratcheted
+    # minimum block level from frame to frame)
+    import tempfile
+    nseq = max(1, rounds // 5)
+    for r in range(nseq):
+        rng = np.random.default_rng(seed0 + 100000 + r)
+        spec = random_options(rng)
+        q = float(rng.choice([8.0, 20.0, 45.0]))
+        colour = bool(rng.integers(0, 2))
+        first = random_image(rng, colour)
+        hdr = first.split(b"\n")[1].split()
+        w, h = int(hdr[0]), int(hdr[1])
+        nfr = int(rng.integers(2, 5))
+        with tempfile.TemporaryDirectory() as td:
+            names = []
+            for f in range(nfr):
+                a = rng.integers(0, 256, (h, w, 3 if colour else 1)).astype(np.float64)
+                base = np.frombuffer(first[len(first) - w * h * (3 if colour else 1):], np.uint8).reshape(h, w, -1)
+                img = np.clip(0.85 * base + 0.15 * a + 3 * f, 0, 255).astype(np.uint8)
+                pth = os.path.join(td, "f%02d.%s" % (f, "ppm" if colour else "pgm"))
+                (synth.write_ppm if colour else synth.write_pgm)(pth, img if colour else img[:, :, 0])
+                names.append(pth)
+            og, oo = gpu.cli_options(pattern="i"), ora.cli_options(pattern="i")
+            apply(og, spec); apply(oo, spec)
+            rg = gpu.fiasco_coder(names, os.path.join(td, "g.fco"), q, og)
+            gmsg = gpu.error_message()
+            ro = ora.fiasco_coder(names, os.path.join(td, "o.fco"), q, oo)
+            n += 1
+            if rg == 0 and ro == 1 and "device coder" in gmsg:
+                refused += 1
+            elif rg != ro or (rg == 1 and open(os.path.join(td, "g.fco"), "rb").read() != open(os.path.join(td, "o.fco"), "rb").read()):
+                bad += 1
+                print("MISMATCH sequence seed %d spec %s q %s colour %s frames %d: rc %d/%d (%s)"
+                      % (seed0 + 100000 + r, spec, q, colour, nfr, rg, ro, gmsg), flush=True)
     print("fuzz: %d frames in %d rounds, %d mismatches, %d refused by the device (with message), %.1f s"
           % (n, rounds, bad, refused, time.time() - t0))
     return 1 if bad else 0

@@ -32,8 +32,10 @@ extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t s
  * second-domain retry */
 static bool needs_big_variant(const fa_cparams *cp)
 {
+    unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
     return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
-           || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search;
+           || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search
+           || (cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF;
 }
 
 static fiasco_amd_stats g_stats;
@@ -98,7 +100,7 @@ extern "C" void fiasco_amd_release_memory(void)
 
 struct Layout {
     size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
-           final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, pix16, total;
+           final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, snap, pix16, total;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
@@ -135,6 +137,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(pool_states, (size_t) (P + 8) * 2);
     CARVE(pos, (size_t) (PA + 8) * 2);
     CARVE(hits, (size_t) (PA + 8) * 4);
+    CARVE(snap, (size_t) 26 * 2 * 82 * 16);          /* aac snapshots of the big build: depth x 2 x n16 */
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -156,9 +159,9 @@ static int device_supported(const fa_job *job, char *why, size_t n)
     if (cp->max_elements > 5) { snprintf(why, n, "more than 5 vectors per block are not supported by the device coder"); return 0; }
     {
         unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
-        if ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF) {
+        if ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF_BIG) {
             snprintf(why, n, "coefficient model too large for the device coder "
-                             "(block levels x mantissa symbols > %d)", FC_MAXCOEFF);
+                             "(block levels x mantissa symbols > %d)", FC_MAXCOEFF_BIG);
             return 0;
         }
     }
@@ -266,6 +269,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pool_states = (int16_t *) (base + L.pool_states);
     F.pos = (int16_t *) (base + L.pos);
     F.hits = (int *) (base + L.hits);
+    F.snap_hbm = fs.big ? (void *) (base + L.snap) : nullptr;
 }
 
 /* allocate the slab of one frame for capacity fs.P and upload its pixel plane */
@@ -288,9 +292,9 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         return 0;
     }
     fill_frame(fs, job);
-    if (fs.F.coeff_size > FC_MAXCOEFF || fs.F.dcs > FC_MAXSYM || fs.F.sy > FC_MAXSYM || fs.F.ML > 26) {
+    if (fs.F.coeff_size > (fs.big ? FC_MAXCOEFF_BIG : FC_MAXCOEFF) || fs.F.dcs > FC_MAXSYM || fs.F.sy > FC_MAXSYM || fs.F.ML > 26) {
         snprintf(job->errmsg, sizeof job->errmsg,
-                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", FC_MAXCOEFF);
+                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", FC_MAXCOEFF_BIG);
         slab_release(fs.base, fs.bytes); fs.base = nullptr;
         fs.done = true; fs.rejected = true;      /* permanent: not a matter of free HBM */
         return 0;

@@ -28,7 +28,8 @@
 #define FC_MAXED    5
 #define FC_BLOCK    256         /* threads per frame workgroup */
 #define FC_MAXDEPTH 22          /* recursion depth bound: level <= 26, lc_min >= 6 */
-#define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS */
+#define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */
+#define FC_MAXCOEFF_BIG 640     /* big build: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
 #define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
 #define FC_MAXBASIS 16          /* states of the initial basis */
 
@@ -72,6 +73,7 @@ typedef struct DevFrame {
     uint8_t *level_of_state, *domain_type;
     uint16_t *x, *y;
     uint8_t *ycol;         /* [2][PA] y_column of wfa_t, kept per state ID across removals */
+    void    *snap_hbm;     /* big build: home of the aac model snapshots when they outgrow LDS */
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     int     *hits;         /* [P] edge-target histogram for the chroma domain list */

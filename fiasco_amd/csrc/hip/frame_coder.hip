@@ -142,7 +142,7 @@ struct MPState {
  * that a snapshot is a short run of 128-bit LDS copies */
 struct __attribute__((aligned(16))) CoeffBuf {
     short tot[16];                 /* coeff_nt <= 16 contexts */
-    short cnt[FC_MAXCOEFF];
+    short cnt[FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF];
 };
 #if FC_VARIANT_BIG
 #define SNAP_POOL16 1290           /* uint4 slots for aac snapshots: depth x 2 x n16 */
@@ -171,6 +171,7 @@ struct Sh {
     Pool     pool;
     CoeffBuf cb;
     uint4    snap_pool[SNAP_POOL16];
+    uint4   *snap;                 /* snapshots live here: snap_pool, or HBM when they outgrow it */
     int      n16;                  /* uint4 per aac snapshot */
     __attribute__((aligned(16))) unsigned tm[TM_WORDS];
     __attribute__((aligned(16))) unsigned snap_tm[SNAP_TM_WORDS];
@@ -922,15 +923,21 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
 }
 
+#if FC_VARIANT_BIG
+#define SNAP(sh) ((sh).snap)
+#else
+#define SNAP(sh) ((sh).snap_pool)
+#endif
+
 /* the same snapshots taken by the whole workgroup around a linear-combination search
  * (codec/subdivide.c:188-237): before it, models -> slot 0 (+ tree model); after it, models ->
  * slot 1 and slot 0 -> models.  One 16-byte element per lane. */
 __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, int ML)
 {
     const int tid = threadIdx.x;
-    if (tid < sh.n16) sh.snap_pool[(depth * 2 + 0) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
-    else if (tid >= 64 && tid < 64 + ML)
-        ((uint4 *) (sh.snap_tm + depth * 4 * ML))[tid - 64] = ((const uint4 *) sh.tm)[tid - 64];
+    if (tid < sh.n16) SNAP(sh)[(depth * 2 + 0) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
+    else if (tid >= 96 && tid < 96 + ML)           /* n16 <= 82 (FC_MAXCOEFF_BIG), ML <= 26 */
+        ((uint4 *) (sh.snap_tm + depth * 4 * ML))[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
     else if (tid == 128) fr.pool0 = sh.pool;
 }
 
@@ -938,8 +945,8 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
 {
     const int tid = threadIdx.x;
     if (tid < sh.n16) {
-        sh.snap_pool[(depth * 2 + 1) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
-        ((uint4 *) &sh.cb)[tid] = sh.snap_pool[(depth * 2 + 0) * sh.n16 + tid];
+        SNAP(sh)[(depth * 2 + 1) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
+        ((uint4 *) &sh.cb)[tid] = SNAP(sh)[(depth * 2 + 0) * sh.n16 + tid];
     } else if (tid == 128) {
         fr.pool_lc = sh.pool;
         sh.pool = fr.pool0;
@@ -982,12 +989,12 @@ __device__ __forceinline__ void copy16(uint4 *dst, const uint4 *src, int n)
 
 __device__ void snap_save(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    copy16(sh.snap_pool + (depth * 2 + which) * sh.n16, (const uint4 *) &sh.cb, sh.n16);
+    copy16(SNAP(sh) + (depth * 2 + which) * sh.n16, (const uint4 *) &sh.cb, sh.n16);
 }
 
 __device__ void snap_load(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    copy16((uint4 *) &sh.cb, sh.snap_pool + (depth * 2 + which) * sh.n16, sh.n16);
+    copy16((uint4 *) &sh.cb, SNAP(sh) + (depth * 2 + which) * sh.n16, sh.n16);
 }
 
 __device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML)
@@ -1445,12 +1452,16 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         }
         /* aac model, all-ones (coeff.c:297-310) */
         sh.n16 = (32 + 2 * F.coeff_size + 15) / 16;
-        if ((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16
+#if FC_VARIANT_BIG
+        /* snapshots that outgrow LDS (wide level window x many mantissa symbols) live in HBM */
+        sh.snap = (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16 && F.snap_hbm ? (uint4 *) F.snap_hbm : sh.snap_pool;
+#endif
+        if (((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16 && !(FC_VARIANT_BIG && F.snap_hbm))
             || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16
             || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
             || F.level - F.lc_min + 2 > FC_MAXDEPTH)
             sh.failed = FC_ERR_INTERNAL;
-        for (int i = 0; i < FC_MAXCOEFF; i++) sh.cb.cnt[i] = 0;
+        for (int i = 0; i < (FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF); i++) sh.cb.cnt[i] = 0;
         for (int i = 0; i < 16; i++) sh.cb.tot[i] = 0;
         for (int i = 0; i < F.coeff_size; i++) sh.cb.cnt[i] = 1;
         sh.cb.tot[0] = (short) F.dcs;

@@ -71,6 +71,7 @@ def main():
     gpu.set_verbosity(0); ora.set_verbosity(0)
     bad = 0
     refused = 0
+    reasons = set()
     n = 0
     t0 = time.time()
     for r in range(rounds):
@@ -92,6 +93,9 @@ def main():
         for i, (g, e) in enumerate(zip(got, exp)):
             n += 1
             if g is None and e is not None and "device coder" in gmsg:
+                if refused == 0 or gmsg not in reasons:
+                    reasons.add(gmsg)
+                    print("refused:", gmsg, flush=True)
                 refused += 1                      # outside the device scope, said so
                 continue
             if g != e:

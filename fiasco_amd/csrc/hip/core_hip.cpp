@@ -35,7 +35,11 @@ static bool needs_big_variant(const fa_cparams *cp)
     unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
     return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
            || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search
-           || (cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF;
+           || (cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF
+           /* per-depth aac snapshots beyond the default build's LDS pool (840 x 16 bytes,
+            * frame_coder.hip SNAP_POOL16): the big build parks them in HBM */
+           || (cp->level - cp->lc_min_level + 3) * 2
+              * ((32 + 2 * ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs) + 15) / 16) > 840;
 }
 
 static fiasco_amd_stats g_stats;

@@ -165,6 +165,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = lib.get_stats()
+    root = batch.stats(0)          # coder-side error of the survey frame
     batch.free()
     assert out is not None and all(o is not None for o in out), lib.error_message()
 
@@ -204,7 +205,8 @@ def main():
                        "kernel_only_frames_per_s": nframes / (kernel_ms / 1e3) * world if kernel_ms else None,
                        "pcie_inclusive_frames_per_s": world * F / (dt / a.steps + t_stage),
                        "stage_seconds_per_batch": t_stage,
-                       "parity": "stream md5 of survey frame == reference (%s)" % REF_MD5_SEED1234[:12]},
+                       "parity": "stream md5 of survey frame == reference (%s)" % REF_MD5_SEED1234[:12],
+                       "estimated_psnr_db": root["psnr_db"] if root else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(F, a.width, a.height),
                          "kernel": "fiasco_frame_kernel", "avg_launch_ms": avg_kernel_s * 1e3,

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats",
     "fiasco_amd_release_memory",
 ]
 
@@ -244,6 +244,22 @@ class Batch:
             else:
                 res.append(None)
         return res
+
+    def stats(self, i, band=0):
+        """fiasco_amd_batch_stats: root-range costs / squared error of frame i (band 0..2) of the
+        last finished pass and the coder-side PSNR the reference reports (codec/coder.c:918-923)."""
+        import math
+        c = ctypes
+        f = self.lib.L.fiasco_amd_batch_stats
+        f.argtypes = [c.c_void_p, c.c_uint, c.c_uint, c.POINTER(c.c_float), c.POINTER(c.c_float),
+                      c.POINTER(c.c_uint), c.POINTER(c.c_uint)]
+        f.restype = c.c_int
+        costs, err, w, h = c.c_float(), c.c_float(), c.c_uint(), c.c_uint()
+        if not f(self.handle, i, band, costs, err, w, h):
+            return None
+        mse = err.value / w.value / h.value
+        return {"costs": costs.value, "err": err.value, "width": w.value, "height": h.value,
+                "psnr_db": 10.0 * math.log10(255.0 * 255.0 / mse) if mse > 0 else float("inf")}
 
     def free(self):
         if self.handle:

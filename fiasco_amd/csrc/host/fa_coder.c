@@ -372,6 +372,18 @@ struct fiasco_amd_batch {
     void      *staged;        /* core handle: inputs resident where the core computes */
 };
 
+int fiasco_amd_batch_stats(const fiasco_amd_batch_t *b, unsigned i, unsigned band,
+                           float *costs, float *err, unsigned *width, unsigned *height)
+{
+    if (!b || i >= b->n || band > 2 || !b->jobs[i].status) return 0;
+    if (band && !b->jobs[i].image->color) return 0;
+    if (costs)  *costs  = b->jobs[i].stats[band].costs;
+    if (err)    *err    = b->jobs[i].stats[band].err;
+    if (width)  *width  = b->jobs[i].image->width;
+    if (height) *height = b->jobs[i].image->height;
+    return 1;
+}
+
 void fiasco_amd_batch_free(fiasco_amd_batch_t *b)
 {
     unsigned i;

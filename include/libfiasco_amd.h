@@ -139,6 +139,12 @@ int  fiasco_amd_batch_encode(fiasco_amd_batch_t *batch, unsigned char **out, siz
 int  fiasco_amd_batch_submit(fiasco_amd_batch_t *batch);
 int  fiasco_amd_batch_collect(fiasco_amd_batch_t *batch, unsigned char **out, size_t *out_len,
                               int resubmit);
+/* Root-range statistics of frame i, band 0..2 (Y, Cb, Cr), of the last finished pass: the
+ * figures the reference prints at verbosity 2 (codec/coder.c:918-923): costs, squared error
+ * `err` (coder-side PSNR = 10 log10(255^2 / (err / (width*height)))), and width/height.
+ * Returns 1, or 0 when i/band are out of range or the frame failed.                     */
+int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigned band,
+                            float *costs, float *err, unsigned *width, unsigned *height);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
 
 #ifdef __cplusplus

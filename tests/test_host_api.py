@@ -180,6 +180,32 @@ def test_submit_collect_on_oracle_seam(oracle, inputs):
     b.free()
 
 
+# root-range figures printed by the real reference (`cfiasco -V 2`, codec/coder.c:918-923) for
+# two committed inputs: (squared error, total costs) per band
+REFERENCE_STATS = {
+    "g256": [(3135488.50, 4090260.50)],
+    "c00": [(2026837.50, 2934227.75), (2232672.50, 3808977.50), (2250933.50, 3659728.75)],
+}
+
+
+def check_reference_stats(lib, inputs):
+    import fiasco_amd
+    o = lib.cli_options()
+    b = fiasco_amd.Batch(lib, [inputs.data("g256"), inputs.data("c00")], 20.0, o)
+    assert None not in b.encode()
+    for i, name in enumerate(("g256", "c00")):
+        for band, (err, costs) in enumerate(REFERENCE_STATS[name]):
+            st = b.stats(i, band)
+            assert st is not None and (st["err"], st["costs"]) == (err, costs), (name, band, st)
+    assert b.stats(0, 1) is None and b.stats(2) is None and b.stats(1, 3) is None
+    assert abs(b.stats(0)["psnr_db"] - 31.33) < 0.005      # "PSNR: 31.33 dB" in the reference's log
+    b.free(); o.delete()
+
+
+def test_batch_stats_match_reference_log(oracle, inputs):
+    check_reference_stats(oracle, inputs)
+
+
 def test_stage1_pricing_restructuring(tmp_path):
     """The device prices the run-length part of a candidate from per-step uniform parts
     (mp_device.inc, StepCtx); tests/stage1_pricing_check.c replays that algebra on the CPU

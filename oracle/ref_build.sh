@@ -32,6 +32,9 @@ if [ ! -f "$OUT/cfg/config.h" ]; then
     (cd "$OUT/cfg" && "$REF/configure" --quiet >configure.log 2>&1) || {
         echo "ref_build: configure failed, see $OUT/cfg/configure.log" >&2; exit 1; }
 fi
+# only the generated header is needed; the Makefiles/libtool that configure also emits are not
+# used by this recipe and are not kept
+find "$OUT/cfg" -mindepth 1 ! -name config.h -delete 2>/dev/null || true
 CFLAGS="-O2 -g -fcommon -fPIC -w -DHAVE_CONFIG_H -I$OUT/cfg -I$REF -I$REF/lib -I$REF/input -I$REF/output -I$REF/codec -DFIASCO_SHARE=\"$REF/data\""
 objs=()
 for f in "$REF"/lib/*.c "$REF"/input/*.c "$REF"/output/*.c "$REF"/codec/*.c; do

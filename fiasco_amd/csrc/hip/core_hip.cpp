@@ -30,8 +30,15 @@ extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t s
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
  * second-domain retry */
-static bool needs_big_variant(const fa_cparams *cp)
+static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
 {
+    /* the default build reads 3 edge slots per label (frame_coder.hip FC_MAXE): a basis file
+     * whose states have more goes to the big build */
+    if (basis)
+        for (unsigned s = 0; s < basis->basis_states; s++)
+            for (unsigned l = 0; l < 2; l++)
+                for (unsigned e = 0; e < 6 && FA_INTO(basis, s, l, e) != FA_NO_EDGE; e++)
+                    if (e >= 3) return true;
     unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
     return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
            || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search
@@ -363,7 +370,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         FrameSlot fs;
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
-        fs.big = needs_big_variant(cp);
+        fs.big = needs_big_variant(cp, jobs[i].wfa);
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;

@@ -85,6 +85,9 @@
 #endif
 #endif
 #define MAXED   FC_MAXED
+/* edges per label a state of this build can have (= max_elements the build accepts): the table
+ * ops read and gather exactly that many term slots (+ the tree child), not the format's 5 */
+#define FC_MAXE (FC_NIP + 1)
 #define NOEDGE  (-1)
 #define RANGE_  (-1)
 #define MAXCOSTS 1e20f
@@ -151,7 +154,11 @@ struct __attribute__((aligned(16))) CoeffBuf {
 #define SNAP_POOL16 840
 #define SNAP_TM_WORDS 2184
 #endif
+#if FC_VARIANT_BIG || FC_VARIANT_WIDE
 #define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
+#else
+#define NBLOCKMIN   64             /* the 256-thread default build is given P <= 3072 (core_hip.cpp) */
+#endif
 #define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
 
 struct RoundBox {                    /* mp_reg.inc: winner of the running step, in LDS */
@@ -433,8 +440,8 @@ __device__ __forceinline__ void auto_tabs(const DevFrame &F, AutoTabs &t)
 /* the automaton rows of one state as they come out of memory: all edge slots are read
  * unconditionally (independent, coalesced loads; what lies behind the terminator is ignored) */
 struct EdgeRows {
-    int   tree[2], rd[2][MAXED];
-    float rw[2][MAXED];
+    int   tree[2], rd[2][FC_MAXE];
+    float rw[2][FC_MAXE];
     int   dt;
 };
 
@@ -450,7 +457,7 @@ __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRow
         /* one scalar base per array, the row offset goes into the lane offset */
         r.tree[l] = ldg(T.tree, us + (unsigned) (l * T.PA));
 #pragma unroll
-        for (int e = 0; e < MAXED; e++) {
+        for (int e = 0; e < FC_MAXE; e++) {
             r.rd[l][e] = ldg(T.into, us + (unsigned) ((l * 6 + e) * T.PA));
             r.rw[l][e] = ldg(T.weight, us + (unsigned) ((l * 6 + e) * T.PA));
         }
@@ -489,8 +496,8 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
              * of a group of slots are in flight together (the chain is latency bound). */
-            int   idx[2][MAXED + 1];
-            float wt[2][MAXED + 1];
+            int   idx[2][FC_MAXE + 1];
+            float wt[2][FC_MAXE + 1];
             unsigned msk[2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
@@ -500,7 +507,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                 wt[l][0] = 1.0f;
                 bool live = true;
 #pragma unroll
-                for (int e = 0; e < MAXED; e++) {
+                for (int e = 0; e < FC_MAXE; e++) {
                     live = live && cur.rd[l][e] != NOEDGE;
                     idx[l][e + 1] = live ? cur.rd[l][e] : 0;
                     wt[l][e + 1] = live ? cur.rw[l][e] : 0.0f;
@@ -509,13 +516,13 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
             }
             constexpr int JG = 4;          /* slots per group: 4 x 12 gathers in flight per lane */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
-                float v[JG][2][MAXED + 1];
+                float v[JG][2][FC_MAXE + 1];
 #pragma unroll
                 for (int jj = 0; jj < JG; jj++)
 #pragma unroll
                     for (int l = 0; l < 2; l++)
 #pragma unroll
-                        for (int i = 0; i <= MAXED; i++) {
+                        for (int i = 0; i <= FC_MAXE; i++) {
                             /* UNCONDITIONAL loads (dead terms read element 0 of the row, slots
                              * past the end re-read the last one): a conditional load becomes a
                              * branch with its own s_waitcnt and the gathers would run one
@@ -531,7 +538,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     for (int l = 0; l < 2; l++) {
                         if (msk[l] & 1u) acc += v[jj][l][0];
 #pragma unroll
-                        for (int i = 1; i <= MAXED; i++)
+                        for (int i = 1; i <= FC_MAXE; i++)
                             if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
                     }
                     stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
@@ -680,13 +687,13 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         const int half = 1 << (l - 1), label = pos >= half;
         const int off = half - 1 + (pos - label * half);
         const int n = sh.gs_n[label];
-        float t[MAXED + 1];
+        float t[FC_MAXE + 1];
 #pragma unroll
-        for (int a = 0; a <= MAXED; a++)                /* all term images in flight */
+        for (int a = 0; a <= FC_MAXE; a++)              /* all term images in flight */
             t[a] = F.img[(size_t) sh.gs_idx[label][a] * F.NI + off];      /* dead slots: state 0 */
         float v = 0;
 #pragma unroll
-        for (int a = 0; a <= MAXED; a++)
+        for (int a = 0; a <= FC_MAXE; a++)
             if (a < n) v = (a == 0 && sh.gs_c[label]) ? t[0] : v + t[a] * sh.gs_w[label][a];
         F.img[(size_t) s * F.NI + i + 1] = v;
         if (l == il) F.imgT[(size_t) pos * P + s] = v;
@@ -720,8 +727,8 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             if (!rows.dt) continue;
             /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
              * once and reused by every table level */
-            int   i2[2][MAXED + 1];
-            float w2[2][MAXED + 1];
+            int   i2[2][FC_MAXE + 1];
+            float w2[2][FC_MAXE + 1];
             unsigned m2[2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
@@ -731,7 +738,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                 w2[l][0] = 1.0f;
                 bool live = true;
 #pragma unroll
-                for (int e = 0; e < MAXED; e++) {
+                for (int e = 0; e < FC_MAXE; e++) {
                     live = live && rows.rd[l][e] != NOEDGE;
                     i2[l][e + 1] = live ? rows.rd[l][e] : 0;
                     w2[l][e + 1] = live ? rows.rw[l][e] : 0.0f;
@@ -767,16 +774,16 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                  * is used; dead term slots of t read a valid dummy entry (no per-lane branch). */
                 GLOBAL_AS const float *G = gram + (size_t) (q - 1) * Pu * Pu;
                 float ip = 0;
-                float g[2][MAXED + 1][MAXED + 1];
+                float g[2][FC_MAXE + 1][FC_MAXE + 1];
 #pragma unroll
                 for (int l = 0; l < 2; l++) {                      /* gathers of both labels */
                     const int na = __builtin_amdgcn_readfirstlane(sh.gs_n[l]);
 #pragma unroll
-                    for (int a = 0; a <= MAXED; a++) {
+                    for (int a = 0; a <= FC_MAXE; a++) {
                         if (a >= na) break;                            /* uniform */
                         const int A = __builtin_amdgcn_readfirstlane(sh.gs_idx[l][a]);
 #pragma unroll
-                        for (int b = 0; b <= MAXED; b++) {
+                        for (int b = 0; b <= FC_MAXE; b++) {
                             const int bb = i2[l][b];
                             const bool mirror = bb > A && bb >= flim;     /* gram_load() */
                             g[l][a][b] = ldg(G, (unsigned) (mirror ? bb * Pu + A : A * Pu + bb));
@@ -788,12 +795,12 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                     const int na = __builtin_amdgcn_readfirstlane(sh.gs_n[l]);
                     const int ca = __builtin_amdgcn_readfirstlane(sh.gs_c[l]);
 #pragma unroll
-                    for (int a = 0; a <= MAXED; a++) {
+                    for (int a = 0; a <= FC_MAXE; a++) {
                         if (a >= na) break;
                         float sum = 0;
                         if (m2[l] & 1u) sum = g[l][a][0];
 #pragma unroll
-                        for (int b = 1; b <= MAXED; b++)
+                        for (int b = 1; b <= FC_MAXE; b++)
                             if ((m2[l] >> b) & 1u) sum += w2[l][b] * g[l][a][b];
                         if (a == 0 && ca) ip += sum;
                         else ip += sh.gs_w[l][a] * sum;
@@ -1459,7 +1466,8 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         if (((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16 && !(FC_VARIANT_BIG && F.snap_hbm))
             || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16
             || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
-            || F.level - F.lc_min + 2 > FC_MAXDEPTH)
+            || F.level - F.lc_min + 2 > FC_MAXDEPTH
+            || F.max_elements > FC_MAXE)             /* term slots of the table ops */
             sh.failed = FC_ERR_INTERNAL;
         for (int i = 0; i < (FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF); i++) sh.cb.cnt[i] = 0;
         for (int i = 0; i < 16; i++) sh.cb.tot[i] = 0;

@@ -90,7 +90,7 @@ def pmc_traffic(frames, w, h):
         j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     except Exception:
         return None
-    if (frames, w, h) != (768, 1920, 1080):
+    if (frames, w, h) != (j.get("frames_per_launch", 768), 1920, 1080):
         return None
     return j["fetch_bytes_per_launch"] + j["write_bytes_per_launch"]
 
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-gpu", type=int, default=768)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)   # 4 frames per CU x 256 CUs
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames per rank")

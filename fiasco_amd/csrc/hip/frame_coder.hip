@@ -81,7 +81,9 @@
 #define FC_PIXELS    1024
 #define FC_NIP       2
 #ifndef FC_WG_PER_CU
-#define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 3)   /* workgroups (frames) per CU the kernel is built for */
+/* workgroups (frames) per CU the kernel is built for: four 256-thread frames = 4 waves per SIMD,
+ * i.e. at most 128 VGPRs and 40 KB of LDS per frame */
+#define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 4)
 #endif
 #endif
 #define MAXED   FC_MAXED

@@ -1,12 +1,12 @@
 #!/bin/bash
 # developer helper: compile the device coder with line tables and attribute scratch
-# (spill / private array) instructions to source lines
+# (spill / private array) instructions to source lines; extra compiler flags: ISA_FLAGS="-DFC_WG_PER_CU=4"
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=/tmp/fiasco_isa; rm -rf $T; mkdir -p $T; cd $T
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -gline-tables-only \
   -I$R/fiasco_amd/csrc/hip -I$R/fiasco_amd/csrc/host -I$R/include -save-temps \
-  -c $R/fiasco_amd/csrc/hip/frame_coder.hip -o fc.o -Rpass-analysis=kernel-resource-usage 2>&1 \
+  ${ISA_FLAGS:-} -c $R/fiasco_amd/csrc/hip/frame_coder.hip -o fc.o -Rpass-analysis=kernel-resource-usage 2>&1 \
   | grep -E "VGPRs:|ScratchSize|VGPRs Spill|LDS Size|Occupancy" | sed 's/\[-Rpass[^]]*\]//g; s/^.*remark: [^ ]* *//'
 python3 - <<'EOF'
 import re, collections

@@ -164,7 +164,11 @@ struct __attribute__((aligned(16))) CoeffBuf {
 #define TM_WORDS    (4 * 26 + 8)   /* 112 words = 28 uint4 */
 
 struct RoundBox {                    /* mp_reg.inc: winner of the running step, in LDS */
-    float m;                         /* running min_costs */
+    /* running min_costs, one slot per round parity: the owner of round r publishes into
+     * m2[r & 1] and everybody reads it after the round's barrier.  With a single slot a fast
+     * owner of round r + 1 could overwrite the value before a slow wave has read round r's
+     * (seen as rare non-deterministic streams with four frames per CU) */
+    float m2[2];
     int   state;                     /* winning state or -1 */
     int   idx;                       /* its list position (list-based scan only) */
     float cost, mbits, wbits, err, f[MAXED];
@@ -216,7 +220,13 @@ struct Sh {
     float    gs_w[2][MAXED + 1];
     /* parameters the serial lane reads per range, copied from the frame descriptor once (a
      * field of the descriptor is a global-memory round trip in the out-of-line search code) */
-    struct { int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease; } par;
+    struct {
+        int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease;
+        /* the same for the matching pursuit: table bases and quantiser parameters */
+        float *gram, *diag, *ipis; int16_t *pos;
+        int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
+        float rpf_range, dc_range;
+    } par;
     int      states;               /* wfa->states */
     int      flim;                 /* Gram tables: states below it have mirrored entries */
     int      failed;
@@ -265,6 +275,8 @@ __device__ __forceinline__ int qac_shift(int index)
 /* ------------------------------------------------------------------ table access */
 
 #define GRAM(F, q)   ((F).gram + (size_t) (q) * (F).P * (F).P)
+/* the same through the LDS copy of the table base (no descriptor read on the hot path) */
+#define PGRAM(sh, q)  ((sh).par.gram + (size_t) (q) * (sh).par.P * (sh).par.P)
 #define TREE(F, s, l)        ((F).tree[(l) * (F).PA + (s)])
 #define INTO(F, s, l, e)     ((F).into[((l) * 6 + (e)) * (F).PA + (s)])
 #define WEIGHT(F, s, l, e)   ((F).weight[((l) * 6 + (e)) * (F).PA + (s)])
@@ -516,7 +528,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
-            constexpr int JG = 4;          /* slots per group: 4 x 12 gathers in flight per lane */
+            constexpr int JG = 4;          /* slots per group: 4 x 2 x (FC_MAXE + 1) gathers in flight per lane (8: -5 %) */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
                 float v[JG][2][FC_MAXE + 1];
 #pragma unroll
@@ -1482,6 +1494,11 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         sh.par.lc_max = F.lc_max; sh.par.width = F.width; sh.par.height = F.height;
         sh.par.limit_states = F.limit_states; sh.par.PA = F.PA; sh.par.P = F.P; sh.par.ML = F.ML;
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
+        sh.par.gram = F.gram; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
+        sh.par.max_elements = F.max_elements; sh.par.rpf_mant = F.rpf_mant; sh.par.dc_mant = F.dc_mant;
+        sh.par.sy = F.sy; sh.par.dcs = F.dcs; sh.par.gl0 = F.gl0; sh.par.images_level = F.images_level;
+        sh.par.lc_min_opt = F.lc_min; sh.par.trace_on = F.trace != nullptr;
+        sh.par.rpf_range = F.rpf_range; sh.par.dc_range = F.dc_range;
         sh.band = 0; sh.lc_min = F.lc_min; sh.after_chroma = 0; sh.ystates = 0;
         push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */

@@ -47,5 +47,10 @@ for r in range(reps):
         print("  dbg:", " ".join("%.3g" % (x / max(ok, 1)) for x in st.dbg))
     if not ok:
         print(lib.error_message())
+    # replicas of one input must give one stream: anything else is a race on the device
+    var = [len(set(out[i] for i in range(j, n, nd))) for j in range(nd)]
+    if max(var) > 1:
+        print("  NON-DETERMINISTIC: distinct streams per distinct input:", var)
+print("  sizes per input:", [len(out[j]) if out[j] else None for j in range(nd)])
 print("  md5 frame0:", hashlib.md5(out[0]).hexdigest() if out[0] else None, "sizes", sorted(set(len(o) for o in out if o))[:4])
 batch.free()

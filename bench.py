@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path over one batch of synthetic frames per GPU: F
 independent 1920x1080 grayscale frames (BASELINE config 2: CLI defaults, -q 20, 8x8 px
 minimum range blocks, default dictionary), all in flight at once -- one persistent
-workgroup per frame, three frames per CU -- through the staged C-ABI entries
+workgroup per frame, four frames per CU -- through the staged C-ABI entries
 fiasco_amd_batch_stage() (parse PNM, upload the pixel planes: inputs resident in HBM,
 OUTSIDE the timed region) and fiasco_amd_batch_encode() (timed: device partition search +
 matching pursuit, download of the automata, host-side .fco entropy writer).  `value` is

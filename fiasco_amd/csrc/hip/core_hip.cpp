@@ -7,9 +7,10 @@
  *          pool, upload the int16 pixel plane; the basis automaton travels inside the
  *          DevFrame descriptor.  After stage the inputs are resident in HBM.
  *  run   : ONE persistent kernel launch with one workgroup per staged frame (all frames in
- *          flight at once), then one packed device->host copy per frame of the finished
- *          automaton for the host stream writer.  Frames whose state capacity guess was too
- *          small are re-staged with a larger slab and relaunched.
+ *          flight at once); every frame packs its finished automaton into a per-launch
+ *          buffer, which comes down with ONE device->host copy on a second stream (double
+ *          buffered: the next launch does not wait for it).  Frames whose state capacity
+ *          guess was too small are re-staged with a larger slab and relaunched.
  *  There is no CPU fallback: without a usable GPU every job fails with an error message.
  */
 #include <hip/hip_runtime.h>
@@ -214,6 +215,14 @@ struct Staged {
     std::vector<std::pair<size_t, size_t>> to_unpack;   /* (slot, offset in pinned) */
     char  *pinned = nullptr;       /* host staging buffer for the automaton downloads */
     size_t pinned_bytes = 0;
+    /* packed automata of a launch (DevFrame.pack_dst), double buffered: launch i + 1 writes the
+     * other buffer while the copy of launch i is still on its way to the host */
+    char  *d_pack[2] = { nullptr, nullptr };
+    size_t d_pack_bytes[2] = { 0, 0 }, pack_need = 0;
+    int    parity = 0;
+    bool   packed = false, copy_pending = false;
+    std::vector<size_t> pack_off;
+    hipStream_t cstream = nullptr;
 };
 
 static void fill_frame(FrameSlot &fs, const fa_job *job)
@@ -332,6 +341,8 @@ extern "C" void fa_core_unstage(void *h)
     for (size_t k = 0; k < S->slots.size(); k++)
         if (S->slots[k].base) slab_release(S->slots[k].base, S->slots[k].bytes);
     if (S->d_frames) (void) hipFree(S->d_frames);
+    if (S->cstream) { (void) hipStreamSynchronize(S->cstream); (void) hipStreamDestroy(S->cstream); }
+    for (int i = 0; i < 2; i++) if (S->d_pack[i]) (void) hipFree(S->d_pack[i]);
     if (S->pinned) (void) hipHostFree(S->pinned);
     if (S->ev0) (void) hipEventDestroy(S->ev0);
     if (S->ev1) (void) hipEventDestroy(S->ev1);
@@ -525,6 +536,34 @@ static bool launch_wave(Staged *S)
     const char *trace_path = getenv("FIASCO_AMD_TRACE");
     const int trace_cap = 400000;
     for (size_t b = 0; b < batch.size(); b++) hf[b] = S->slots[batch[b]].F;
+    {   /* where every frame packs its finished automaton */
+        S->parity ^= 1;
+        char *&pack = S->d_pack[S->parity];
+        S->pack_off.assign(batch.size(), 0);
+        size_t need = 0;
+        for (size_t b = 0; b < batch.size(); b++) {
+            const Layout &L = S->slots[batch[b]].L;
+            S->pack_off[b] = need;
+            need += align_up(L.pool_states - L.tree, 256);
+        }
+        S->pack_need = need;
+        if (need > S->d_pack_bytes[S->parity]) {
+            if (pack) (void) hipFree(pack);
+            pack = nullptr; S->d_pack_bytes[S->parity] = 0;
+            if (hipMalloc((void **) &pack, need) == hipSuccess) S->d_pack_bytes[S->parity] = need;
+            else { pack = nullptr; (void) hipGetLastError(); }
+        }
+        if (!S->cstream && hipStreamCreateWithFlags(&S->cstream, hipStreamNonBlocking) != hipSuccess) {
+            S->cstream = nullptr; (void) hipGetLastError();
+        }
+        S->packed = pack != nullptr && S->cstream != nullptr;
+        for (size_t b = 0; b < batch.size(); b++) {
+            const FrameSlot &fs = S->slots[batch[b]];
+            hf[b].pack_src = fs.base + fs.L.tree;
+            hf[b].pack_bytes = (unsigned) (fs.L.pool_states - fs.L.tree);
+            hf[b].pack_dst = S->packed ? pack + S->pack_off[b] : nullptr;
+        }
+    }
     if (trace_path && hipMalloc((void **) &S->d_trace, sizeof(FcTrace) * trace_cap) == hipSuccess) {
         hf[0].trace = S->d_trace; hf[0].trace_cap = trace_cap;
     }
@@ -583,23 +622,37 @@ static void complete_wave(Staged *S)
         S->broken = true;
         return;
     }
-    /* all automata of the launch come down with async copies into one pinned buffer */
+    /* all automata of the launch come down into one pinned buffer: one copy of the packed
+     * buffer on the copy stream (not waited for here: the next launch may start first), or --
+     * without a packed buffer -- one async copy per frame */
     std::vector<size_t> off(batch.size(), (size_t) -1);
     {
         size_t need = 0;
+        if (S->packed) {
+            need = S->pack_need;
+            for (size_t b = 0; b < batch.size(); b++) if (hf[b].status == FC_OK) off[b] = S->pack_off[b];
+        } else
         for (size_t b = 0; b < batch.size(); b++)
             if (hf[b].status == FC_OK) {
                 const Layout &L = S->slots[batch[b]].L;
                 off[b] = need;
                 need += align_up(L.pool_states - L.tree, 256);
             }
+        if (S->copy_pending) { (void) hipStreamSynchronize(S->cstream); S->copy_pending = false; }
         if (need > S->pinned_bytes) {
             if (S->pinned) (void) hipHostFree(S->pinned);
             S->pinned = nullptr; S->pinned_bytes = 0;
             if (hipHostMalloc((void **) &S->pinned, need, hipHostMallocDefault) == hipSuccess) S->pinned_bytes = need;
             else { S->pinned = nullptr; (void) hipGetLastError(); }
         }
-        if (S->pinned) {
+        if (S->pinned && S->packed) {
+            if (hipMemcpyAsync(S->pinned, S->d_pack[S->parity], need, hipMemcpyDeviceToHost, S->cstream) == hipSuccess)
+                S->copy_pending = true;
+            else {
+                (void) hipGetLastError();
+                for (size_t b = 0; b < batch.size(); b++) off[b] = (size_t) -1;
+            }
+        } else if (S->pinned) {
             for (size_t b = 0; b < batch.size(); b++)
                 if (off[b] != (size_t) -1) {
                     const FrameSlot &fs = S->slots[batch[b]];
@@ -649,6 +702,7 @@ static void complete_wave(Staged *S)
 
 static void flush_unpack(Staged *S)
 {
+    if (S->copy_pending) { (void) hipStreamSynchronize(S->cstream); S->copy_pending = false; }
     for (size_t i = 0; i < S->to_unpack.size(); i++)
         S->good += collect(S, S->slots[S->to_unpack[i].first], S->pinned + S->to_unpack[i].second);
     S->to_unpack.clear();

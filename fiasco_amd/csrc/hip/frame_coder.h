@@ -77,6 +77,13 @@ typedef struct DevFrame {
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     int     *hits;         /* [P] edge-target histogram for the chroma domain list */
+    /* finished automaton, packed: at the end of the frame the workgroup copies its automaton
+     * arrays (tree .. ycol, one contiguous part of the slab) to pack_dst, a per-launch buffer
+     * that holds the automata of all frames back to back -- ONE device->host copy per launch,
+     * and the next launch does not have to wait for it (core_hip.cpp).  pack_dst may be null. */
+    const void *pack_src;
+    void    *pack_dst;
+    unsigned pack_bytes;
     /* ---- results ---- */
     int      status;
     int      states, root_state;

@@ -1563,6 +1563,12 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         F.lc_min_out = sh.lc_min;
         F.status = sh.failed ? sh.failed : FC_OK;
     }
+    if (F.pack_dst) {                         /* the automaton for the host writer, packed */
+        const uint4 *src = (const uint4 *) F.pack_src;
+        uint4 *dst = (uint4 *) F.pack_dst;
+        const unsigned n16 = F.pack_bytes / 16;
+        for (unsigned i = tid; i < n16; i += B) dst[i] = src[i];
+    }
 }
 
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, hipStream_t stream)

@@ -27,17 +27,23 @@
  *  with -ffp-contract=off (no FMA).  double log2() is evaluated once per call into small
  *  LDS tables (the rate models only ever need log2 of count/total ratios).
  *
- *  Device scope of this build: gray and colour I frames (bands: codec/coder.c:738-833),
- *  `rle` pool, `adaptive` coefficients, optimisation level 0, lc_min_level > images_level == 5
- *  (CLI defaults).
+ *  Device scope: gray and colour I frames (bands: codec/coder.c:738-833), `rle` pool,
+ *  `adaptive` coefficients; the default build of this file covers the CLI defaults (block
+ *  levels 6..10, <= 3 vectors), FC_VARIANT_BIG the other option sets (see below).
+ *
+ *  Register budget: the default build is compiled for 4 workgroups per CU, i.e. <= 128 VGPRs.
+ *  The persistent loop makes EVERYTHING loop invariant in the compiler's eyes; what must not be
+ *  computed once at kernel entry and kept for the kernel's lifetime is hidden from the hoisting
+ *  (opaque thread index in the scan, out-of-line log2 tables, descriptor fields through
+ *  sh.par in LDS).  tests/isa_spills.sh shows what still goes to scratch and from which line.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
 #include "frame_coder.h"
 
-/* FC_VARIANT_WIDE: 512 threads per frame instead of 256 -- for launches with fewer frames than
- * CUs x 3 and for frames with more states than 12 x 256 (4K): twice the lanes per frame, 18
+/* FC_VARIANT_WIDE: 512 threads per frame instead of 256 -- for launches with no more frames than
+ * CUs and for frames with more states than 12 x 256 (4K): twice the lanes per frame, 18
  * register slots per lane (9216 states), one workgroup per CU */
 #ifndef FC_VARIANT_WIDE
 #define FC_VARIANT_WIDE 0
@@ -54,7 +60,7 @@
 #define FC_KREG 12
 #endif
 /* Two builds of this file (csrc/Makefile): the default one for the CLI's -z 0 geometry (block
- * levels 6..10, <= 3 vectors: 3 frames per CU) and FC_VARIANT_BIG for everything else the
+ * levels 6..10, <= 3 vectors: 4 frames per CU) and FC_VARIANT_BIG for everything else the
  * device supports (block levels 4..12, <= 5 vectors, second-domain retry: 2 frames per CU). */
 #ifndef FC_VARIANT_BIG
 #define FC_VARIANT_BIG 0

@@ -6,6 +6,8 @@ sizes, RPF mantissas/ranges, chroma options -- encoded by both libraries through
 fiasco_amd_encode_batch; any byte difference is reported with the seed that reproduces it.
 
 usage: fuzz_parity.py [rounds] [frames_per_round] [seed0]
+environment: FUZZ_BIG=1 sizes up to 1000 x 800; FUZZ_REPL=n every frame n times in one launch (the
+replicas must agree: a full device exposes timing-dependent faults that single frames hide)
 """
 import os
 import sys
@@ -86,8 +88,16 @@ def main():
         else:
             os.environ.pop("FIASCO_AMD_NO_WIDE", None)
         print("round seed %d spec %s q %s" % (seed0 + r, spec, q), flush=True)
-        got = gpu.encode_batch(frames, q, og)
+        repl = int(os.environ.get("FUZZ_REPL", "1"))    # FUZZ_REPL=n: every frame n times in the launch
+        got_all = gpu.encode_batch(frames * repl, q, og)
         gmsg = gpu.error_message()
+        got = got_all[:len(frames)]
+        for k in range(1, repl):                         # replicas must agree (timing-dependent faults)
+            for i in range(len(frames)):
+                if got_all[k * len(frames) + i] != got[i]:
+                    bad += 1
+                    print("MISMATCH seed %d frame %d: replica %d differs from replica 0 (non-deterministic)"
+                          % (seed0 + r, i, k), flush=True)
         exp = ora.encode_batch(frames, q, oo)
         og.delete(); oo.delete()
         for i, (g, e) in enumerate(zip(got, exp)):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer helper: device-vs-oracle stream + per-call trace comparison
-# usage: tests/gpu_quick.sh [name ...]   (names: g96 g256 n512 g720 g1080 c00 c128 k720 k1080)
+# usage: tests/gpu_quick.sh [name ...]   (names: g96 g256 n512 g720 g1080 c00 c128 c512 k720 k1080)
 # extra cfiasco arguments for both coders: QUICK_ARGS="-z 1"
 set -u
 cd "$(dirname "$0")/.."

@@ -154,7 +154,9 @@ class Library:
         o.set_chroma_quality(kw.get("chroma_qfactor", 2.0), kw.get("chroma_dictionary", 40))
         o.set_smoothing(kw.get("smooth", 70))
         o.set_progress_meter(progress)
-        o.set_tiling(FIASCO_TILING_VARIANCE_DSC, kw.get("tiling_exponent", 4))
+        o.set_tiling({"desc-variance": FIASCO_TILING_VARIANCE_DSC, "asc-variance": FIASCO_TILING_VARIANCE_ASC,
+                      "asc-spiral": FIASCO_TILING_SPIRAL_ASC, "desc-spiral": FIASCO_TILING_SPIRAL_DSC}
+                     [kw.get("tiling_method", "desc-variance")], kw.get("tiling_exponent", 4))
         if optimize <= 0:
             o.set_optimizations(6, 10, 3, dictionary_size, 0)
         else:

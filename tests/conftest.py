@@ -120,6 +120,10 @@ def options_from_args(lib, args):
         elif a == "--rpf-range": rpf["r"] = float(v)
         elif a == "--dc-rpf-mantissa": rpf["dm"] = int(v)
         elif a == "--dc-rpf-range": rpf["dr"] = float(v)
+        elif a == "--chroma-qfactor": kw["chroma_qfactor"] = float(v)
+        elif a == "--chroma-dictionary": kw["chroma_dictionary"] = int(v)
+        elif a == "--tiling-exponent": kw["tiling_exponent"] = int(v)
+        elif a == "--tiling-method": kw["tiling_method"] = v
         else: raise ValueError(a)
         i += 2
     o = lib.cli_options(optimize=optimize, dictionary_size=dict_size, **kw)

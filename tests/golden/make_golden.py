@@ -37,6 +37,9 @@ INPUTS = {
     "g720":     ("synth", dict(w=1280, h=720, seed=1234), False),
     "g1080":    ("synth", dict(w=1920, h=1080, seed=1234), False),
     "c00":      ("color_c", dict(w=320, h=256, f=0), False),
+    "c256":     ("color_c", dict(w=256, h=192, f=0), False),   # (128 x 128 colour: the reference
+    "c256b":    ("color_c", dict(w=256, h=192, f=1), False),   #  fails, "Can't write more than 121 weights")
+    "g100x70":  ("synth", dict(w=100, h=70, seed=9), True),
 }
 
 CASES = [
@@ -66,6 +69,18 @@ CASES = [
     ("g1080_q20", ["g1080"], []),
     ("c00_q20", ["c00"], []),
     ("c00_z1", ["c00"], ["-z", "1"]),
+    # colour with committed inputs, chroma options, the minimum-level carry between the frames
+    # of a colour stream (codec/coder.c:785-797), options the CLI passes through unchanged
+    ("c256_q20", ["c256"], []),
+    ("c256_z2", ["c256"], ["-z", "2"]),
+    ("c256_chroma", ["c256"], ["--chroma-qfactor", "3.5", "--chroma-dictionary", "5"]),
+    ("seq2_color_i", ["c256", "c256b"], ["--pattern", "i"]),
+    ("seq2_color_i_rev", ["c256b", "c256"], ["--pattern", "i"]),
+    ("g256_dict8", ["g256"], ["--dictionary-size", "8"]),
+    ("g256_tiling", ["g256"], ["--tiling-exponent", "2", "--tiling-method", "asc-variance"]),
+    ("g256_ranges", ["g256"], ["--rpf-range", "1.0", "--dc-rpf-range", "2.0"]),
+    ("g96x64_q90", ["g96x64"], ["-q", "90"]),
+    ("g100x70_q20", ["g100x70"], []),
 ]
 
 # Streams of the reference for the scope rows that come NEXT (intra prediction,

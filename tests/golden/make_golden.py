@@ -40,6 +40,9 @@ INPUTS = {
     "c256":     ("color_c", dict(w=256, h=192, f=0), False),   # (128 x 128 colour: the reference
     "c256b":    ("color_c", dict(w=256, h=192, f=1), False),   #  fails, "Can't write more than 121 weights")
     "g100x70":  ("synth", dict(w=100, h=70, seed=9), True),
+    "flat64":   ("flat", dict(w=64, h=64, v=200), True),
+    "check64":  ("checker", dict(w=64, h=64, cell=4), True),
+    "ramp96":   ("ramp", dict(w=96, h=32), True),
 }
 
 CASES = [
@@ -81,6 +84,15 @@ CASES = [
     ("g256_ranges", ["g256"], ["--rpf-range", "1.0", "--dc-rpf-range", "2.0"]),
     ("g96x64_q90", ["g96x64"], ["-q", "90"]),
     ("g100x70_q20", ["g100x70"], []),
+    # degenerate images: constant, full-swing checkerboard, horizontal ramp
+    ("flat64_q20", ["flat64"], []),
+    ("check64_q20", ["check64"], []),
+    ("check64_z2", ["check64"], ["-z", "2"]),
+    ("ramp96_q20", ["ramp96"], []),
+    ("g256_q1", ["g256"], ["-q", "1"]),
+    ("g256_q99", ["g256"], ["-q", "99"]),
+    ("c256_z1", ["c256"], ["-z", "1"]),
+    ("seq3_gray_i", ["f0_96x64", "f1_96x64", "g96x64"], ["--pattern", "i"]),
 ]
 
 # Streams of the reference for the scope rows that come NEXT (intra prediction,
@@ -104,6 +116,17 @@ def make_input(name):
         return synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"])), "pgm"
     if kind == "noise":
         return synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"])), "pgm"
+    if kind == "flat":
+        import numpy as np
+        return synth.pgm_bytes(np.full((a["h"], a["w"]), a["v"], np.uint8)), "pgm"
+    if kind == "checker":
+        import numpy as np
+        y, x = np.mgrid[0:a["h"], 0:a["w"]]
+        return synth.pgm_bytes((255 * (((x // a["cell"]) + (y // a["cell"])) % 2)).astype(np.uint8)), "pgm"
+    if kind == "ramp":
+        import numpy as np
+        y, x = np.mgrid[0:a["h"], 0:a["w"]]
+        return synth.pgm_bytes((x * 255 // (a["w"] - 1)).astype(np.uint8)), "pgm"
     if kind == "color_c":
         return synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"])), "ppm"
     raise ValueError(kind)

@@ -80,6 +80,8 @@ class Inputs:
                 d = synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"]))
             elif ent["kind"] == "noise":
                 d = synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"]))
+            elif ent["kind"] == "color_k":
+                d = synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"]))
             else:
                 d = synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"]))
         assert hashlib.md5(d).hexdigest() == ent["md5"], "input %s differs from the pinned md5" % name

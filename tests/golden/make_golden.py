@@ -43,6 +43,7 @@ INPUTS = {
     "flat64":   ("flat", dict(w=64, h=64, v=200), True),
     "check64":  ("checker", dict(w=64, h=64, cell=4), True),
     "ramp96":   ("ramp", dict(w=96, h=32), True),
+    "k720":     ("color_k", dict(w=1280, h=720), False),     # SURVEY App. C smooth-chroma generator
 }
 
 CASES = [
@@ -93,6 +94,7 @@ CASES = [
     ("g256_q99", ["g256"], ["-q", "99"]),
     ("c256_z1", ["c256"], ["-z", "1"]),
     ("seq3_gray_i", ["f0_96x64", "f1_96x64", "g96x64"], ["--pattern", "i"]),
+    ("k720_q20", ["k720"], []),
 ]
 
 # Streams of the reference for the scope rows that come NEXT (intra prediction,
@@ -127,6 +129,8 @@ def make_input(name):
         import numpy as np
         y, x = np.mgrid[0:a["h"], 0:a["w"]]
         return synth.pgm_bytes((x * 255 // (a["w"] - 1)).astype(np.uint8)), "pgm"
+    if kind == "color_k":
+        return synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"])), "ppm"
     if kind == "color_c":
         return synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"])), "ppm"
     raise ValueError(kind)

@@ -97,6 +97,28 @@ CASES = [
     ("k720_q20", ["k720"], []),
 ]
 
+# Further pins of the ORACLE against the real reference (small inputs, option sweeps).  The GPU
+# suite does not list them one by one: the device is tied to the oracle on these option sets by
+# the differential fuzzer (tests/fuzz_parity.py).
+ORACLE_CASES = [
+    ("o_g160_z1", ["g160x120"], ["-z", "1"]),
+    ("o_g160_z2", ["g160x120"], ["-z", "2"]),
+    ("o_g100_z2", ["g100x70"], ["-z", "2"]),
+    ("o_g256_m2", ["g256"], ["--rpf-mantissa", "2"]),
+    ("o_g256_m5", ["g256"], ["--rpf-mantissa", "5"]),
+    ("o_g256_dm3", ["g256"], ["--dc-rpf-mantissa", "3"]),
+    ("o_g256_r075", ["g256"], ["--rpf-range", "0.75", "--dc-rpf-range", "0.75"]),
+    ("o_g256_dict1", ["g256"], ["--dictionary-size", "1"]),
+    ("o_g256_dict40_z2", ["g256"], ["--dictionary-size", "40", "-z", "2"]),
+    ("o_n128_q2", ["n128x96"], ["-q", "2"]),
+    ("o_n128_q45_z1", ["n128x96"], ["-q", "45", "-z", "1"]),
+    ("o_g64x32_z2", ["g64x32"], ["-z", "2"]),
+    ("o_g32x32_q60_z2", ["g32x32"], ["-q", "60", "-z", "2"]),
+    ("o_ramp96_z1", ["ramp96"], ["-z", "1"]),
+    # ("flat64", -z 2): the reference itself dies with a segmentation fault on the constant image
+    ("o_c256_q45_chroma", ["c256"], ["-q", "45", "--chroma-qfactor", "1.0", "--chroma-dictionary", "63"]),
+]
+
 # Streams of the reference for the scope rows that come NEXT (intra prediction,
 # P frames).  Neither the oracle nor the device covers them yet -- both refuse these option sets
 # with a message -- so no parity test reads them; they are committed now so that the round that
@@ -170,6 +192,17 @@ def main():
             open(os.path.join(HERE, ent["file"]), "wb").write(data)
         man["cases"].append(ent)
         print("%-16s %6d B  %s" % (cname, len(data), ent["md5"]))
+    man["oracle_cases"] = []
+    for cname, ins, args in ORACLE_CASES:
+        out = os.path.join(TMP, cname + ".fco")
+        cmd = [REF, "--progress-meter", "0"] + args + ["-o", out] + [paths[i] for i in ins]
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            sys.exit("reference failed on %s: %s" % (cname, r.stderr.decode()))
+        data = open(out, "rb").read()
+        man["oracle_cases"].append({"name": cname, "inputs": ins, "args": args, "bytes": len(data),
+                                    "md5": hashlib.md5(data).hexdigest(), "file": None})
+        print("%-28s %6d B  %s" % (cname, len(data), man["oracle_cases"][-1]["md5"]))
     man["next_cases"] = []
     for cname, ins, args in NEXT_CASES:
         out = os.path.join(TMP, cname + ".fco")

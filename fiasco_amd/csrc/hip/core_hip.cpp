@@ -112,7 +112,7 @@ extern "C" void fiasco_amd_release_memory(void)
 
 struct Layout {
     size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
-           final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, snap, pix16, total;
+           final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
@@ -149,6 +149,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(pool_states, (size_t) (P + 8) * 2);
     CARVE(pos, (size_t) (PA + 8) * 2);
     CARVE(hits, (size_t) (PA + 8) * 4);
+    CARVE(ycol0, (size_t) 2 * PA);                   /* initial y_column flags (colour streams) */
     CARVE(snap, (size_t) 26 * 2 * 82 * 16);          /* aac snapshots of the big build: depth x 2 x n16 */
     CARVE(pix16, npix * 2);
 #undef CARVE
@@ -195,6 +196,7 @@ struct FrameSlot {
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
+    std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
 };
 
 struct Staged {
@@ -286,6 +288,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.domain_type = (uint8_t *) (base + L.domain_type);
     F.x = (uint16_t *) (base + L.x); F.y = (uint16_t *) (base + L.y);
     F.ycol = (uint8_t *) (base + L.ycol);
+    F.ycol0 = job->ycol_carry ? (const uint8_t *) (base + L.ycol0) : nullptr;
     F.pool_states = (int16_t *) (base + L.pool_states);
     F.pos = (int16_t *) (base + L.pos);
     F.hits = (int *) (base + L.hits);
@@ -326,6 +329,18 @@ static int stage_slot(Staged *S, FrameSlot &fs)
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
             return 0;
         }
+    if (job->ycol_carry) {                 /* [cap][2] on the host, [2][PA] on the device */
+        const fa_wfa *w = job->wfa;
+        fs.ycol_host.assign((size_t) 2 * fs.PA, 0);
+        for (unsigned s = 0; s < w->cap && s < (unsigned) fs.PA; s++)
+            for (int l = 0; l < 2; l++) fs.ycol_host[(size_t) l * fs.PA + s] = w->y_column[s * 2 + l];
+        if (hipMemcpyAsync(fs.base + fs.L.ycol0, fs.ycol_host.data(), fs.ycol_host.size(),
+                           hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: y_column upload failed");
+            slab_release(fs.base, fs.bytes); fs.base = nullptr;
+            return 0;
+        }
+    }
     fs.staged = true;
     return 1;
 }
@@ -454,6 +469,10 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
             }
         }
     }
+    if (F.color)                         /* the flags of EVERY state id: the next frame of a stream
+                                          * starts from them (fa_job.ycol_carry) */
+        for (unsigned s = 0; s < w->cap && s < (unsigned) P; s++)
+            for (int l = 0; l < 2; l++) w->y_column[s * 2 + l] = ycol[(size_t) l * P + s];
     w->states = ns;
     w->root_state = (unsigned) F.root_state;
     job->stats[0].costs = F.costs; job->stats[0].err = F.err;

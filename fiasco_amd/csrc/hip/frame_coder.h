@@ -73,6 +73,8 @@ typedef struct DevFrame {
     uint8_t *level_of_state, *domain_type;
     uint16_t *x, *y;
     uint8_t *ycol;         /* [2][PA] y_column of wfa_t, kept per state ID across removals */
+    const uint8_t *ycol0;  /* what ycol starts from: the flags the previous frame of a colour stream
+                            * left behind (fa_job.ycol_carry); null = zeros (fresh wfa_t) */
     void    *snap_hbm;     /* big build: home of the aac model snapshots when they outgrow LDS */
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */

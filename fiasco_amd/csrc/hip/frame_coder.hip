@@ -1510,7 +1510,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */
     }
     if (F.color)                              /* calloc'ed in the reference (codec/wfa.h) */
-        for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = 0;
+        for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = F.ycol0 ? F.ycol0[i] : (uint8_t) 0;
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
     if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;

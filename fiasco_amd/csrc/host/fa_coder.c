@@ -240,6 +240,7 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     unsigned char **bufs = NULL;
     size_t *lens = NULL;
     unsigned carry_min_level;
+    uint8_t *carry_ycol = NULL;
 
     memset(&wi, 0, sizeof wi);
     templ = (!inputname || !inputname[0] || strcmp(inputname[0], "-") == 0) ? default_input : inputname;
@@ -309,6 +310,7 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
 
     fa_bw_init(&out); have_out = 1;
     carry_min_level = cp.lc_min_level;
+    carry_ycol = NULL;
     for (i = 0; i < nframes; ) {
         /* Gray frames are independent and go to the core as one batch; colour frames carry
          * lc_min_level from frame to frame (codec/coder.c:785-797) and go one by one. */
@@ -321,6 +323,11 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
             if (!ims[k]) { failed = 1; break; }
             cp.lc_min_level = carry_min_level;
             if (!prepare_job(&jobs[k], ims[k], &cp, op->basis_name)) failed = 1;
+            else if (color && carry_ycol) {
+                /* the y_column flags the previous frame left behind (see fa_job.ycol_carry) */
+                memcpy(jobs[k].wfa->y_column, carry_ycol, (size_t) jobs[k].wfa->cap * 2);
+                jobs[k].ycol_carry = 1;
+            }
         }
         if (!failed) {
             good = (unsigned) fa_core_encode_frames(nb, jobs);
@@ -336,6 +343,10 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
                                 op->delta_domains, &out))
                 failed = 1;
             carry_min_level = jobs[k].lc_min_level_out;
+            if (color) {
+                if (!carry_ycol) carry_ycol = (uint8_t *) malloc((size_t) jobs[k].wfa->cap * 2);
+                if (carry_ycol) memcpy(carry_ycol, jobs[k].wfa->y_column, (size_t) jobs[k].wfa->cap * 2);
+            }
         }
         for (k = 0; k < nb; k++) { fa_wfa_free(jobs[k].wfa); fa_image_free(ims[k]); }
         free(jobs); free(ims);
@@ -351,6 +362,7 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     }
     rc = 1;
 done:
+    free(carry_ycol);
     if (have_out) fa_bw_free(&out);
     if (fout && fout != stdout) fclose(fout);
     else if (fout) fflush(fout);

@@ -165,6 +165,13 @@ typedef struct fa_job {
     char              errmsg[160];/* out */
     unsigned          lc_min_level_out; /* out: value of options.lc_min_level after the
                                            frame (colour carry, codec/coder.c:785-797) */
+    int               ycol_carry; /* in: wfa->y_column holds what the previous frame of the
+                                     stream left there.  The reference keeps ONE wfa_t for a
+                                     whole stream and remove_states() (codec/wfalib.c:277-310)
+                                     does not clear y_column, so the flags of a colour frame
+                                     show through on states of the next frame that are not made
+                                     by init_new_state (the three join states).  On return the
+                                     array holds this frame's flags for EVERY state id. */
 } fa_job;
 
 /* THE SEAM.  Encode n independent frames.  Returns number of successful jobs.

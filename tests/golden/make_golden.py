@@ -44,6 +44,12 @@ INPUTS = {
     "check64":  ("checker", dict(w=64, h=64, cell=4), True),
     "ramp96":   ("ramp", dict(w=96, h=32), True),
     "k720":     ("color_k", dict(w=1280, h=720), False),     # SURVEY App. C smooth-chroma generator
+    # colour frames (48 x 70 and 74 x 138) found by tests/fuzz_oracle_vs_reference.py (seeds 1431,
+    # 1187): coded as one stream, y_column flags of a frame show through on the next one
+    "carry48_a": ("file", dict(ext="ppm"), True), "carry48_b": ("file", dict(ext="ppm"), True),
+    "carry48_c": ("file", dict(ext="ppm"), True),
+    "carry74_a": ("file", dict(ext="ppm"), True), "carry74_b": ("file", dict(ext="ppm"), True),
+    "carry74_c": ("file", dict(ext="ppm"), True),
 }
 
 CASES = [
@@ -95,6 +101,13 @@ CASES = [
     ("c256_z1", ["c256"], ["-z", "1"]),
     ("seq3_gray_i", ["f0_96x64", "f1_96x64", "g96x64"], ["--pattern", "i"]),
     ("k720_q20", ["k720"], []),
+    ("seq3_color_carry48", ["carry48_a", "carry48_b", "carry48_c"],
+     ["-q", "99", "-z", "2", "--dictionary-size", "300", "--rpf-mantissa", "5", "--dc-rpf-mantissa", "5",
+      "--rpf-range", "0.75", "--dc-rpf-range", "2.0", "--chroma-qfactor", "3.5", "--chroma-dictionary", "1",
+      "--pattern", "i"]),
+    ("seq3_color_carry74", ["carry74_a", "carry74_b", "carry74_c"],
+     ["--dictionary-size", "8", "--rpf-mantissa", "4", "--dc-rpf-mantissa", "2", "--rpf-range", "2.0",
+      "--dc-rpf-range", "1.5", "--chroma-qfactor", "3.5", "--chroma-dictionary", "1", "--pattern", "i"]),
 ]
 
 # Further pins of the ORACLE against the real reference (small inputs, option sweeps).  The GPU
@@ -140,6 +153,8 @@ def make_input(name):
         return synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"])), "pgm"
     if kind == "noise":
         return synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"])), "pgm"
+    if kind == "file":
+        return open(os.path.join(HERE, name + "." + a["ext"]), "rb").read(), a["ext"]
     if kind == "flat":
         import numpy as np
         return synth.pgm_bytes(np.full((a["h"], a["w"]), a["v"], np.uint8)), "pgm"

@@ -37,7 +37,8 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
     "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats",
-    "fiasco_amd_release_memory",
+    "fiasco_amd_release_memory", "fiasco_amd_batch_upload",
+    "fiasco_amd_selftest_log2",
 ]
 
 
@@ -220,6 +221,19 @@ class Batch:
                                                options.handle if options else None)
         if not self.handle:
             raise FiascoError(lib.error_message())
+
+    def upload(self, pnm_list):
+        """fiasco_amd_batch_upload: new frames for every slot (host PNM buffers -> pinned ->
+        HBM, not waited for); the next submit / collect(resubmit=True) encodes them."""
+        c = ctypes
+        assert len(pnm_list) == self.n
+        f = self.lib.L.fiasco_amd_batch_upload
+        f.argtypes = [c.c_void_p, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t)]
+        f.restype = c.c_int
+        bufs = (c.c_char_p * self.n)(*pnm_list)
+        lens = (c.c_size_t * self.n)(*[len(b) for b in pnm_list])
+        if not f(self.handle, bufs, lens):
+            raise FiascoError(self.lib.error_message())
 
     def submit(self):
         """fiasco_amd_batch_submit: start a pass over the resident inputs, do not wait."""

@@ -57,8 +57,12 @@ extern "C" void fiasco_amd_reset_stats(void) { memset(&g_stats, 0, sizeof g_stat
 extern "C" const char *fa_core_name(void) { return "hip-gfx950"; }
 
 /* one process per GPU: bind this process's coder to a device of the node */
+extern "C" void fiasco_amd_release_memory(void);
 extern "C" int fiasco_amd_set_device(int device)
 {
+    int cur = -1;
+    /* the slab pool holds memory of the device it was allocated on: never carry it over */
+    if (hipGetDevice(&cur) == hipSuccess && cur != device) fiasco_amd_release_memory();
     if (hipSetDevice(device) != hipSuccess) {
         fa_set_error("libfiasco_amd: cannot select HIP device %d", device);
         return 0;
@@ -67,6 +71,93 @@ extern "C" int fiasco_amd_set_device(int device)
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* ------------------------------------------------------------------ log2 self test
+ *
+ * The rate models price symbols with double log2 of a float probability p = count / (float)
+ * total (codec/coeff.c:232-237, codec/domain-pool.c:772, codec/bintree.c:67).  The host side
+ * of the reference evaluates it with glibc, the device with ROCm's ocml; bit parity of the
+ * streams needs both to return the same DOUBLE for every argument that can occur.  Every such
+ * argument is a float in (0, 1] (and 1 - p is one in [0, 1)), so the claim can be checked
+ * exhaustively: this entry evaluates log2((double) p) on the device for all floats of an
+ * exponent range and compares the doubles bit for bit with glibc's on the host. */
+#include <math.h>
+#include <pthread.h>
+
+__global__ void selftest_log2_kernel(unsigned first_bits, unsigned n, double *out)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log2((double) __uint_as_float(first_bits + i));
+}
+
+struct L2Task { const double *dev; unsigned first_bits, n, t, nt; unsigned long long dd, df; unsigned bad; };
+
+static void *l2_thread(void *arg)
+{
+    L2Task *k = (L2Task *) arg;
+    for (unsigned i = k->t; i < k->n; i += k->nt) {
+        unsigned bits = k->first_bits + i;
+        float p; memcpy(&p, &bits, 4);
+        double h = log2((double) p), d = k->dev[i];
+        if (memcmp(&h, &d, 8) != 0) {
+            k->dd++;
+            if ((float) -h != (float) -d) { if (!k->df) k->bad = bits; k->df++; }
+        }
+    }
+    return nullptr;
+}
+
+/* floats with biased exponent in [exp_lo, exp_hi] (126 = [0.5, 1)); returns 1 when the run
+ * completed.  n_double / n_float: arguments whose double result / whose (float) -log2 differ. */
+extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
+                                        unsigned long long *n_double, unsigned long long *n_float,
+                                        float *first_bad)
+{
+    const unsigned CH = 1u << 23;                  /* one binade per launch */
+    double *d_out = nullptr, *h_out = nullptr;
+    unsigned long long checked = 0, dd = 0, df = 0;
+    unsigned bad = 0;
+    if (exp_lo < 1) exp_lo = 1;
+    if (exp_hi > 127) exp_hi = 127;
+    if (hipMalloc((void **) &d_out, (size_t) CH * 8) != hipSuccess
+        || hipHostMalloc((void **) &h_out, (size_t) CH * 8, hipHostMallocDefault) != hipSuccess) {
+        fa_set_error("selftest: HIP error: %s", hipGetErrorString(hipGetLastError()));
+        if (d_out) (void) hipFree(d_out);
+        return 0;
+    }
+    for (unsigned e = exp_lo; e <= exp_hi; e++) {
+        const unsigned first = e << 23;
+        const unsigned n = e == 127 ? 1u : CH;     /* 1.0 is the largest probability */
+        hipLaunchKernelGGL(selftest_log2_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, first, n, d_out);
+        if (hipMemcpy(h_out, d_out, (size_t) n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            fa_set_error("selftest: HIP error: %s", hipGetErrorString(hipGetLastError()));
+            (void) hipFree(d_out); (void) hipHostFree(h_out);
+            return 0;
+        }
+        enum { NT = 16 };
+        pthread_t th[NT];
+        L2Task task[NT];
+        int started[NT] = { 0 };
+        for (unsigned t = 0; t < NT; t++) {
+            task[t] = L2Task{ h_out, first, n, t, NT, 0, 0, 0 };
+            if (t) started[t] = pthread_create(&th[t], nullptr, l2_thread, &task[t]) == 0;
+        }
+        l2_thread(&task[0]);
+        for (unsigned t = 1; t < NT; t++) { if (started[t]) pthread_join(th[t], nullptr); else l2_thread(&task[t]); }
+        for (unsigned t = 0; t < NT; t++) {
+            dd += task[t].dd;
+            if (task[t].df && !df) bad = task[t].bad;
+            df += task[t].df;
+        }
+        checked += n;
+    }
+    (void) hipFree(d_out); (void) hipHostFree(h_out);
+    if (n_checked) *n_checked = checked;
+    if (n_double) *n_double = dd;
+    if (n_float) *n_float = df;
+    if (first_bad) memcpy(first_bad, &bad, 4);
+    return 1;
+}
 
 /* ------------------------------------------------------------------ slab pool */
 
@@ -87,11 +178,18 @@ static char *slab_acquire(size_t bytes, size_t *got)
         return p;
     }
     char *p = nullptr;
-    if (hipMalloc((void **) &p, bytes) != hipSuccess) {
+    size_t free_b = 0, total_b = 0;
+    /* leave a reserve for the launch's own buffers (descriptors, packed automata, uploads) */
+    const size_t reserve = (size_t) 768 << 20;
+    bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= bytes + reserve;
+    if (!fits || hipMalloc((void **) &p, bytes) != hipSuccess) {
         /* pool may be holding slabs of other sizes: drop them and try once more */
+        (void) hipGetLastError();
+        if (g_free.empty()) return nullptr;
         for (size_t i = 0; i < g_free.size(); i++) (void) hipFree(g_free[i].base);
         g_free.clear();
-        if (hipMalloc((void **) &p, bytes) != hipSuccess) return nullptr;
+        fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= bytes + reserve;
+        if (!fits || hipMalloc((void **) &p, bytes) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     }
     *got = bytes;
     return p;
@@ -197,6 +295,8 @@ struct FrameSlot {
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
+    const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
+    const int16_t *ext_next = nullptr;   /* ... of the frames the NEXT pass encodes */
 };
 
 struct Staged {
@@ -225,6 +325,17 @@ struct Staged {
     bool   packed = false, copy_pending = false;
     std::vector<size_t> pack_off;
     hipStream_t cstream = nullptr;
+    /* replacement inputs (fa_core_upload_buffer / _commit): pinned host staging memory, two
+     * device buffers used alternately (the running pass reads one, the upload fills the
+     * other), a stream of their own and the event the next launch waits for */
+    char  *up_host = nullptr;
+    size_t up_host_bytes = 0;
+    char  *up_dev[2] = { nullptr, nullptr };
+    size_t up_dev_bytes[2] = { 0, 0 };
+    int    up_parity = 0;
+    bool   up_pending = false;
+    hipStream_t ustream = nullptr;
+    hipEvent_t  ev_up = nullptr;
 };
 
 static void fill_frame(FrameSlot &fs, const fa_job *job)
@@ -322,7 +433,8 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         fs.done = true; fs.rejected = true;      /* permanent: not a matter of free HBM */
         return 0;
     }
-    for (int b = 0; b < bands; b++)
+    if (fs.ext_pix) fs.F.pix16 = fs.ext_pix;       /* the planes live outside the slab already */
+    for (int b = 0; b < bands && !fs.ext_pix; b++)
         if (hipMemcpyAsync(fs.base + fs.L.pix16 + (size_t) b * npix * 2, job->image->pixels[b], npix * 2,
                            hipMemcpyHostToDevice, S->stream) != hipSuccess) {
             snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
@@ -359,6 +471,10 @@ extern "C" void fa_core_unstage(void *h)
     if (S->cstream) { (void) hipStreamSynchronize(S->cstream); (void) hipStreamDestroy(S->cstream); }
     for (int i = 0; i < 2; i++) if (S->d_pack[i]) (void) hipFree(S->d_pack[i]);
     if (S->pinned) (void) hipHostFree(S->pinned);
+    if (S->ustream) { (void) hipStreamSynchronize(S->ustream); (void) hipStreamDestroy(S->ustream); }
+    if (S->ev_up) (void) hipEventDestroy(S->ev_up);
+    if (S->up_host) (void) hipHostFree(S->up_host);
+    for (int i = 0; i < 2; i++) if (S->up_dev[i]) (void) hipFree(S->up_dev[i]);
     if (S->ev0) (void) hipEventDestroy(S->ev0);
     if (S->ev1) (void) hipEventDestroy(S->ev1);
     if (S->stream) (void) hipStreamDestroy(S->stream);
@@ -405,8 +521,6 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
     }
     /* stage as many frames as HBM holds; the rest is staged by run() as slabs free up */
     for (size_t k = 0; k < S->slots.size(); k++) {
-        size_t free_b = 0, total_b = 0;
-        (void) hipMemGetInfo(&free_b, &total_b);
         if (!stage_slot(S, S->slots[k])) {
             if (S->slots[k].rejected) continue;   /* outside the device scope: message recorded */
             if (k == 0) continue;          /* does not fit even alone: error already recorded */
@@ -417,6 +531,77 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
     (void) hipStreamSynchronize(S->stream);
     S->ok = true;
     return S;
+}
+
+/* ---- replacement inputs for a staged batch (a stream of batches) ---- */
+
+extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
+{
+    Staged *S = (Staged *) h;
+    if (!S || !S->ok || !bytes) return nullptr;
+    /* the previous upload has left this memory long ago (a whole pass lies in between) */
+    if (S->ustream) (void) hipStreamSynchronize(S->ustream);
+    if (bytes > S->up_host_bytes) {
+        if (S->up_host) (void) hipHostFree(S->up_host);
+        S->up_host = nullptr; S->up_host_bytes = 0;
+        if (hipHostMalloc((void **) &S->up_host, bytes, hipHostMallocDefault) != hipSuccess) {
+            S->up_host = nullptr; (void) hipGetLastError();
+            return nullptr;
+        }
+        S->up_host_bytes = bytes;
+    }
+    return (int16_t *) S->up_host;
+}
+
+extern "C" int fa_core_upload_commit(void *h)
+{
+    Staged *S = (Staged *) h;
+    if (!S || !S->ok || !S->up_host) return 0;
+    if (!S->ustream && hipStreamCreateWithFlags(&S->ustream, hipStreamNonBlocking) != hipSuccess) {
+        S->ustream = nullptr; (void) hipGetLastError(); return 0;
+    }
+    if (!S->ev_up && hipEventCreateWithFlags(&S->ev_up, hipEventDisableTiming) != hipSuccess) {
+        S->ev_up = nullptr; (void) hipGetLastError(); return 0;
+    }
+    /* the buffer the RUNNING pass does not read */
+    const int p = S->up_parity ^ 1;
+    size_t lo = (size_t) -1, hi = 0;
+    for (size_t k = 0; k < S->slots.size(); k++) {
+        const fa_image *im = S->jobs[S->slots[k].job].image;
+        const size_t npix = (size_t) im->width * im->height * (im->color ? 3 : 1);
+        const size_t o = (size_t) ((const char *) im->pixels[0] - S->up_host);
+        if ((const char *) im->pixels[0] < S->up_host || o + npix * 2 > S->up_host_bytes) {
+            fa_set_error("upload: frame planes lie outside the upload buffer");
+            return 0;
+        }
+        if (o < lo) lo = o;
+        if (o + npix * 2 > hi) hi = o + npix * 2;
+    }
+    if (hi <= lo) return 1;                      /* nothing the device can encode */
+    if (S->up_host_bytes > S->up_dev_bytes[p]) {
+        if (S->up_dev[p]) (void) hipFree(S->up_dev[p]);
+        S->up_dev[p] = nullptr; S->up_dev_bytes[p] = 0;
+        if (hipMalloc((void **) &S->up_dev[p], S->up_host_bytes) != hipSuccess) {
+            S->up_dev[p] = nullptr; (void) hipGetLastError();
+            fa_set_error("out of HBM: no room for %.1f MiB of replacement frames", S->up_host_bytes / 1048576.0);
+            return 0;
+        }
+        S->up_dev_bytes[p] = S->up_host_bytes;
+    }
+    if (hipMemcpyAsync(S->up_dev[p] + lo, S->up_host + lo, hi - lo, hipMemcpyHostToDevice, S->ustream) != hipSuccess
+        || hipEventRecord(S->ev_up, S->ustream) != hipSuccess) {
+        fa_set_error("HIP error: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
+    }
+    for (size_t k = 0; k < S->slots.size(); k++) {
+        FrameSlot &fs = S->slots[k];
+        const fa_image *im = S->jobs[fs.job].image;
+        /* taken over by the next submit: a re-encode of the RUNNING pass (capacity guess too
+         * small) still reads that pass's frames */
+        fs.ext_next = (const int16_t *) (S->up_dev[p] + ((const char *) im->pixels[0] - S->up_host));
+    }
+    S->up_pending = true;
+    return 1;
 }
 
 /* copy the finished automaton of one frame back into the job's fa_wfa */
@@ -536,8 +721,9 @@ static bool launch_wave(Staged *S)
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
     size_t group_n[4] = { 0, 0, 0, 0 };
     {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus <= 0)
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
         const bool few = batch.size() <= (size_t) cus && !getenv("FIASCO_AMD_NO_WIDE");
         std::vector<size_t> ordered;
@@ -632,10 +818,10 @@ static void complete_wave(Staged *S)
     }
     if (S->d_trace) { (void) hipFree(S->d_trace); S->d_trace = nullptr; }
     if (fail) {
+        const char *why = hipGetErrorString(hipGetLastError());   /* reading it clears it: once */
         for (size_t b = 0; b < batch.size(); b++) {
             FrameSlot &fs = S->slots[batch[b]];
-            snprintf(S->jobs[fs.job].errmsg, sizeof S->jobs[fs.job].errmsg, "HIP error: %s",
-                     hipGetErrorString(hipGetLastError()));
+            snprintf(S->jobs[fs.job].errmsg, sizeof S->jobs[fs.job].errmsg, "HIP error: %s", why);
             fs.done = true;
         }
         S->broken = true;
@@ -689,6 +875,7 @@ static void complete_wave(Staged *S)
         void *tr_keep = fs.F.trace;
         fs.F = hf[b];
         fs.F.trace = (FcTrace *) tr_keep; fs.F.trace_cap = 0;
+        if (fs.ext_pix) fs.F.pix16 = fs.ext_pix;
         size_t cap = align_up(job->cp.limit_states, 64);
         if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
             /* capacity guess too small: bigger slab, same inputs, encode again */
@@ -736,6 +923,17 @@ extern "C" int fa_core_submit(void *h)
     /* job status / automata of the previous pass stay readable until fa_core_finish() */
     for (size_t k = 0; k < S->slots.size(); k++) S->slots[k].done = false;
     S->good = 0; S->broken = false;
+    if (S->up_pending) {
+        /* a new pass takes over the replacement inputs: the launch waits for their transfer,
+         * descriptors are uploaded by every launch anyway */
+        (void) hipStreamWaitEvent(S->stream, S->ev_up, 0);
+        for (size_t k = 0; k < S->slots.size(); k++) {
+            FrameSlot &fs = S->slots[k];
+            if (fs.ext_next) { fs.ext_pix = fs.ext_next; fs.F.pix16 = fs.ext_pix; }
+        }
+        S->up_parity ^= 1;
+        S->up_pending = false;
+    }
     S->inflight = launch_wave(S);
     return 1;
 }

@@ -268,9 +268,15 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     for (;; nframes++) {
         char *nm = input_name(templ, nframes, &err);
         if (!nm) { if (err) goto done; break; }
-        names = (char **) realloc(names, (nframes + 1) * sizeof *names);
-        bufs  = (unsigned char **) realloc(bufs, (nframes + 1) * sizeof *bufs);
-        lens  = (size_t *) realloc(lens, (nframes + 1) * sizeof *lens);
+        {
+            char **n2 = (char **) realloc(names, (nframes + 1) * sizeof *names);
+            unsigned char **b2 = (unsigned char **) realloc(bufs, (nframes + 1) * sizeof *bufs);
+            size_t *l2 = (size_t *) realloc(lens, (nframes + 1) * sizeof *lens);
+            if (n2) names = n2;
+            if (b2) bufs = b2;
+            if (l2) lens = l2;
+            if (!n2 || !b2 || !l2) { free(nm); fa_set_error("Out of memory!"); goto done; }
+        }
         names[nframes] = nm; bufs[nframes] = NULL; lens[nframes] = 0;
     }
     for (i = 0; i < nframes; i++) {
@@ -379,6 +385,8 @@ struct fiasco_amd_batch {
     unsigned   n;
     fa_job    *jobs;
     fa_image **ims;
+    fa_image **prev_ims;      /* frames of the pass before the last upload: a pass that was
+                               * submitted with them may still be in flight */
     fa_info   *infos;
     int        normal_domains, delta_domains;
     void      *staged;        /* core handle: inputs resident where the core computes */
@@ -404,9 +412,10 @@ void fiasco_amd_batch_free(fiasco_amd_batch_t *b)
     for (i = 0; i < b->n; i++) {
         if (b->jobs && b->jobs[i].wfa) fa_wfa_free(b->jobs[i].wfa);
         if (b->ims) fa_image_free(b->ims[i]);
+        if (b->prev_ims) fa_image_free(b->prev_ims[i]);
         if (b->infos) fa_info_free(&b->infos[i]);
     }
-    free(b->jobs); free(b->ims); free(b->infos);
+    free(b->jobs); free(b->ims); free(b->prev_ims); free(b->infos);
     free(b);
 }
 
@@ -428,10 +437,18 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
         return NULL;
     }
     b = (fiasco_amd_batch_t *) calloc(1, sizeof *b);
+    if (b) {
+        b->jobs  = (fa_job *) calloc(n ? n : 1, sizeof *b->jobs);
+        b->ims   = (fa_image **) calloc(n ? n : 1, sizeof *b->ims);
+        b->infos = (fa_info *) calloc(n ? n : 1, sizeof *b->infos);
+    }
+    if (!b || !b->jobs || !b->ims || !b->infos) {
+        fa_set_error("Out of memory!");
+        if (defaults) fiasco_c_options_delete(defaults);
+        fiasco_amd_batch_free(b);
+        return NULL;
+    }
     b->n = n;
-    b->jobs  = (fa_job *) calloc(n ? n : 1, sizeof *b->jobs);
-    b->ims   = (fa_image **) calloc(n ? n : 1, sizeof *b->ims);
-    b->infos = (fa_info *) calloc(n ? n : 1, sizeof *b->infos);
     b->normal_domains = op->normal_domains;
     b->delta_domains  = op->delta_domains;
     for (i = 0; i < n; i++) {
@@ -453,7 +470,8 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
 /* the entropy writer of every finished frame (output/write.c:53-119 in the reference): a pure
  * function of the frame's automaton, so the frames of a batch are written by a few host
  * threads */
-typedef struct { fiasco_amd_batch_t *b; unsigned char **outv; size_t *out_len; unsigned t, nt, good; } wr_task;
+typedef struct { fiasco_amd_batch_t *b; unsigned char **outv; size_t *out_len; unsigned t, nt, good;
+                 char err[256]; } wr_task;
 
 /* developer aid: FIASCO_DUMP_WFA=<file> appends a text dump of every automaton handed to the
  * writer (diff the dumps of two cores to find what the per-call traces cannot show) */
@@ -491,9 +509,15 @@ static void *wr_thread(void *arg)
                            b->delta_domains, &out)) {
             w->out_len[i] = fa_bw_finish(&out);
             w->outv[i] = (unsigned char *) malloc(w->out_len[i]);
-            memcpy(w->outv[i], out.buf, w->out_len[i]);
-            w->good++;
-        }
+            if (w->outv[i]) {
+                memcpy(w->outv[i], out.buf, w->out_len[i]);
+                w->good++;
+            } else {
+                w->out_len[i] = 0;
+                snprintf(w->err, sizeof w->err, "Out of memory!");
+            }
+        } else if (!w->err[0])       /* the last-error string is per thread: hand it to the caller */
+            snprintf(w->err, sizeof w->err, "%s", fiasco_get_error_message());
         fa_bw_free(&out);
     }
     return NULL;
@@ -511,7 +535,7 @@ static unsigned write_streams(fiasco_amd_batch_t *b, unsigned char **outv, size_
     if (nt < 1) nt = 1;
     for (t = 0; t < nt; t++) {
         task[t].b = b; task[t].outv = outv; task[t].out_len = out_len;
-        task[t].t = t; task[t].nt = nt; task[t].good = 0;
+        task[t].t = t; task[t].nt = nt; task[t].good = 0; task[t].err[0] = 0;
     }
     {
         int started[MAXT] = { 0 };
@@ -523,10 +547,99 @@ static unsigned write_streams(fiasco_amd_batch_t *b, unsigned char **outv, size_
             else wr_thread(&task[t]);        /* no thread: the caller does that share */
         }
     }
-    for (t = 0; t < nt; t++) good += task[t].good;
+    for (t = 0; t < nt; t++) {
+        good += task[t].good;
+        if (task[t].err[0]) fa_set_error("%s", task[t].err);     /* published after the join */
+    }
     for (i = 0; i < b->n; i++)
         if (!b->jobs[i].status) fa_set_error("%s", b->jobs[i].errmsg);
     return good;
+}
+
+/* ---- replacing the inputs of a staged batch while a pass runs (a stream of batches) ---- */
+
+typedef struct { fiasco_amd_batch_t *b; const unsigned char *const *pnm; const size_t *len;
+                 int16_t *buf; const size_t *off; fa_image **out; unsigned t, nt, bad; char err[256]; } up_task;
+
+static void *up_thread(void *arg)
+{
+    up_task *u = (up_task *) arg;
+    fiasco_amd_batch_t *b = u->b;
+    unsigned i;
+    for (i = u->t; i < b->n; i += u->nt) {
+        const fa_image *old = b->ims[i];
+        u->out[i] = fa_image_from_pnm_into(u->pnm[i], u->len[i], "<memory>", old->width, old->height,
+                                           old->color, u->buf + u->off[i]);
+        if (!u->out[i]) {
+            if (!u->bad) snprintf(u->err, sizeof u->err, "%s", fiasco_get_error_message());
+            u->bad++;
+        }
+    }
+    return NULL;
+}
+
+/* New frames for every slot of a staged batch (same sizes, colour model and options): parsed
+ * by a few host threads straight into the core's upload staging memory and copied to the
+ * device without waiting -- call it between submit and collect and the transfer overlaps the
+ * pass that is running; the NEXT submit (or collect with resubmit) encodes the new frames. */
+int fiasco_amd_batch_upload(fiasco_amd_batch_t *b, const unsigned char *const *pnm, const size_t *pnm_len)
+{
+    enum { MAXT = 32 };
+    pthread_t th[MAXT];
+    up_task task[MAXT];
+    int started[MAXT] = { 0 };
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    unsigned nt, t, i, bad = 0;
+    size_t total = 0, *off;
+    int16_t *buf;
+    fa_image **nims;
+
+    if (!b || !b->staged || !b->n) { fa_set_error("Batch is not staged."); return 0; }
+    off = (size_t *) malloc(b->n * sizeof *off);
+    nims = (fa_image **) calloc(b->n, sizeof *nims);
+    if (!off || !nims) { free(off); free(nims); fa_set_error("Out of memory!"); return 0; }
+    for (i = 0; i < b->n; i++) {
+        off[i] = total;
+        total += (size_t) b->ims[i]->width * b->ims[i]->height * (b->ims[i]->color ? 3 : 1);
+    }
+    buf = fa_core_upload_buffer(b->staged, total * sizeof(int16_t));
+    if (!buf) {
+        free(off); free(nims);
+        fa_set_error("No staging memory for %.1f MiB of frames.", total * 2 / 1048576.0);
+        return 0;
+    }
+    nt = b->n / 8;
+    if (nt > MAXT) nt = MAXT;
+    if (ncpu > 1 && nt > (unsigned) ncpu - 1) nt = (unsigned) ncpu - 1;
+    if (nt < 1) nt = 1;
+    for (t = 0; t < nt; t++) {
+        task[t].b = b; task[t].pnm = pnm; task[t].len = pnm_len; task[t].buf = buf; task[t].off = off;
+        task[t].out = nims; task[t].t = t; task[t].nt = nt; task[t].bad = 0; task[t].err[0] = 0;
+    }
+    for (t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, up_thread, &task[t]) == 0;
+    up_thread(&task[0]);
+    for (t = 1; t < nt; t++) {
+        if (started[t]) pthread_join(th[t], NULL);
+        else up_thread(&task[t]);
+    }
+    for (t = 0; t < nt; t++) {
+        bad += task[t].bad;
+        if (task[t].err[0]) fa_set_error("%s", task[t].err);
+    }
+    free(off);
+    if (bad) {                                 /* nothing was replaced */
+        for (i = 0; i < b->n; i++) fa_image_free(nims[i]);
+        free(nims);
+        return 0;
+    }
+    if (b->prev_ims) {
+        for (i = 0; i < b->n; i++) fa_image_free(b->prev_ims[i]);
+        free(b->prev_ims);
+    }
+    b->prev_ims = b->ims;                      /* alive until the next upload */
+    b->ims = nims;
+    for (i = 0; i < b->n; i++) b->jobs[i].image = nims[i];
+    return fa_core_upload_commit(b->staged);
 }
 
 int fiasco_amd_batch_submit(fiasco_amd_batch_t *b)

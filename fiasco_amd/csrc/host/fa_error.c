@@ -14,7 +14,9 @@
 #include "fa_host.h"
 
 static fiasco_verbosity_e g_verbosity = FIASCO_SOME_VERBOSITY; /* lib/error.c:48 */
-static char g_error[1024];
+/* per thread: the writer / upload helpers of a batch run on several threads and publish their
+ * message through the task record after the join (the reference is single threaded) */
+static __thread char g_error[1024];
 
 void fa_set_error(const char *fmt, ...)
 {

@@ -90,9 +90,12 @@ typedef struct fa_image {
     unsigned width, height;
     int      color;
     int16_t *pixels[3];
+    int      borrowed;       /* planes belong to somebody else (upload staging buffer) */
 } fa_image;
 /* parse raw P5/P6 from memory; returns NULL + error message on failure */
 fa_image *fa_image_from_pnm(const unsigned char *buf, size_t len, const char *name);
+fa_image *fa_image_from_pnm_into(const unsigned char *buf, size_t len, const char *name,
+                                 unsigned want_w, unsigned want_h, int want_color, int16_t *planes);
 int       fa_pnm_header(const unsigned char *buf, size_t len, const char *name,
                         unsigned *w, unsigned *h, int *color, size_t *data_off);
 void      fa_image_free(fa_image *im);
@@ -188,6 +191,14 @@ int   fa_core_finish(void *staged);         /* wait, bring every frame to comple
                                              * automata are then in host memory and the core is
                                              * free for the next submit */
 void  fa_core_unstage(void *staged);
+/* Replacing the inputs of a staged batch while a pass runs (a stream of batches):
+ *   upload_buffer: host staging memory for `bytes` of int16 planes (pinned for the HIP core),
+ *                  valid until the next upload_buffer()/unstage(); NULL = not available
+ *   upload_commit: jobs[i].image now describe the new frames, their planes lie inside the
+ *                  upload buffer; the core copies them to where it computes WITHOUT waiting
+ *                  (overlaps the running pass); the next submit uses them.  1 ok / 0 failed */
+int16_t *fa_core_upload_buffer(void *staged, size_t bytes);
+int   fa_core_upload_commit(void *staged);
 const char *fa_core_name(void);
 
 /* ---------------- bit writer (reference lib/bit-io.c, memory backed) -------------- */

@@ -73,47 +73,92 @@ void fa_image_free(fa_image *im)
 {
     int b;
     if (!im) return;
-    for (b = 0; b < 3; b++) free(im->pixels[b]);
+    if (!im->borrowed)
+        for (b = 0; b < 3; b++) free(im->pixels[b]);
     free(im);
 }
 
-fa_image *fa_image_from_pnm(const unsigned char *buf, size_t len, const char *name)
+/* the pixel conversion of read_image (lib/image.c:365-389) into caller-provided planes */
+static void convert_planes(const unsigned char *px, size_t n, int color, int16_t *const plane[3])
 {
-    unsigned w, h, n, i;
-    int color, b;
-    size_t off;
-    fa_image *im;
-    const unsigned char *px;
-
-    if (!fa_pnm_header(buf, len, name, &w, &h, &color, &off)) return NULL;
-    if ((w & 1) || (h & 1)) {
-        fa_set_error("Width and height of images must be even numbers.");
-        return NULL;
-    }
-    n = w * h;
-    if (len - off < (size_t) n * (color ? 3 : 1)) {
-        fa_set_error("File `%s': I/O Error - %s.", name ? name : "stdin", "truncated pixel data");
-        return NULL;
-    }
-    im = (fa_image *) calloc(1, sizeof *im);
-    if (!im) { fa_set_error("Out of memory!"); return NULL; }
-    im->width = w; im->height = h; im->color = color;
-    for (b = 0; b < (color ? 3 : 1); b++) {
-        im->pixels[b] = (int16_t *) malloc((size_t) n * sizeof(int16_t));
-        if (!im->pixels[b]) { fa_image_free(im); fa_set_error("Out of memory!"); return NULL; }
-    }
-    px = buf + off;
+    size_t i;
     if (!color) {
+        int16_t *g = plane[0];
         for (i = 0; i < n; i++)
-            im->pixels[0][i] = (int16_t) (((int) px[i] - 128) * 16);
+            g[i] = (int16_t) (((int) px[i] - 128) * 16);
     } else {
         for (i = 0; i < n; i++) {
             int r = px[3 * i], g = px[3 * i + 1], bl = px[3 * i + 2];
             /* double arithmetic, left to right, then C truncation toward zero */
-            im->pixels[FA_Y][i]  = (int16_t) ((+0.2989 * r + 0.5866 * g + 0.1145 * bl - 128) * 16);
-            im->pixels[FA_CB][i] = (int16_t) ((-0.1687 * r - 0.3312 * g + 0.5000 * bl) * 16);
-            im->pixels[FA_CR][i] = (int16_t) ((+0.5000 * r - 0.4183 * g - 0.0816 * bl) * 16);
+            plane[FA_Y][i]  = (int16_t) ((+0.2989 * r + 0.5866 * g + 0.1145 * bl - 128) * 16);
+            plane[FA_CB][i] = (int16_t) ((-0.1687 * r - 0.3312 * g + 0.5000 * bl) * 16);
+            plane[FA_CR][i] = (int16_t) ((+0.5000 * r - 0.4183 * g - 0.0816 * bl) * 16);
         }
     }
+}
+
+/* header checks shared by both entry points; sizes are formed in size_t and the dimensions
+ * are bounded before anything is allocated (2^13 = the largest side of a level-26 image) */
+static int checked_header(const unsigned char *buf, size_t len, const char *name,
+                          unsigned *w, unsigned *h, int *color, size_t *off, size_t *n)
+{
+    if (!fa_pnm_header(buf, len, name, w, h, color, off)) return 0;
+    if ((*w & 1) || (*h & 1)) {
+        fa_set_error("Width and height of images must be even numbers.");
+        return 0;
+    }
+    if (*w > (1u << (FA_CAP_LEVEL / 2)) || *h > (1u << (FA_CAP_LEVEL / 2))) {
+        fa_set_error("Image `%s' is too large (at most %u x %u pixels).", name ? name : "stdin",
+                     1u << (FA_CAP_LEVEL / 2), 1u << (FA_CAP_LEVEL / 2));
+        return 0;
+    }
+    *n = (size_t) *w * (size_t) *h;
+    if (len - *off < *n * (*color ? 3 : 1)) {
+        fa_set_error("File `%s': I/O Error - %s.", name ? name : "stdin", "truncated pixel data");
+        return 0;
+    }
+    return 1;
+}
+
+fa_image *fa_image_from_pnm(const unsigned char *buf, size_t len, const char *name)
+{
+    unsigned w, h;
+    int color, b;
+    size_t off, n;
+    fa_image *im;
+
+    if (!checked_header(buf, len, name, &w, &h, &color, &off, &n)) return NULL;
+    im = (fa_image *) calloc(1, sizeof *im);
+    if (!im) { fa_set_error("Out of memory!"); return NULL; }
+    im->width = w; im->height = h; im->color = color;
+    for (b = 0; b < (color ? 3 : 1); b++) {
+        im->pixels[b] = (int16_t *) malloc(n * sizeof(int16_t));
+        if (!im->pixels[b]) { fa_image_free(im); fa_set_error("Out of memory!"); return NULL; }
+    }
+    convert_planes(buf + off, n, color, im->pixels);
+    return im;
+}
+
+/* the same into planes the caller owns (band planes back to back at `planes`): used when the
+ * frames of a batch are replaced while the previous pass still runs (fiasco_amd_batch_upload) */
+fa_image *fa_image_from_pnm_into(const unsigned char *buf, size_t len, const char *name,
+                                 unsigned want_w, unsigned want_h, int want_color, int16_t *planes)
+{
+    unsigned w, h;
+    int color, b;
+    size_t off, n;
+    fa_image *im;
+
+    if (!checked_header(buf, len, name, &w, &h, &color, &off, &n)) return NULL;
+    if (w != want_w || h != want_h || color != want_color) {
+        fa_set_error("`%s': replacement frames must keep the size and colour model of the batch.",
+                     name ? name : "stdin");
+        return NULL;
+    }
+    im = (fa_image *) calloc(1, sizeof *im);
+    if (!im) { fa_set_error("Out of memory!"); return NULL; }
+    im->width = w; im->height = h; im->color = color; im->borrowed = 1;
+    for (b = 0; b < (color ? 3 : 1); b++) im->pixels[b] = planes + (size_t) b * n;
+    convert_planes(buf + off, n, color, im->pixels);
     return im;
 }

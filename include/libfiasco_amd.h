@@ -139,6 +139,14 @@ int  fiasco_amd_batch_encode(fiasco_amd_batch_t *batch, unsigned char **out, siz
 int  fiasco_amd_batch_submit(fiasco_amd_batch_t *batch);
 int  fiasco_amd_batch_collect(fiasco_amd_batch_t *batch, unsigned char **out, size_t *out_len,
                               int resubmit);
+/* A stream of batches: replace the frame of EVERY slot of a staged batch (same number of
+ * frames, same sizes, colour model and options) with new raw PNM buffers in host memory.
+ * The buffers are parsed by a few host threads into pinned staging memory and copied to HBM
+ * without waiting, so a call between submit and collect overlaps the pass that is running;
+ * the next submit (or collect with resubmit) encodes the new frames.  Returns 1 / 0 + message;
+ * on failure the batch keeps its previous frames. */
+int  fiasco_amd_batch_upload(fiasco_amd_batch_t *batch, const unsigned char *const *pnm,
+                             const size_t *pnm_len);
 /* Root-range statistics of frame i, band 0..2 (Y, Cb, Cr), of the last finished pass: the
  * figures the reference prints at verbosity 2 (codec/coder.c:918-923): costs, squared error
  * `err` (coder-side PSNR = 10 log10(255^2 / (err / (width*height)))), and width/height.

@@ -48,6 +48,16 @@ int fiasco_amd_set_device(int device);
  * (hipMalloc of hundreds of MB per frame is slow); this returns the pool to the driver. */
 void fiasco_amd_release_memory(void);
 
+/* Self test of the one libm function the rate models need on both sides of the seam: double
+ * log2 of a float probability (codec/coeff.c:232-237, codec/domain-pool.c:772,
+ * codec/bintree.c:67).  Evaluates it on the device for EVERY float with a biased exponent in
+ * [exp_lo, exp_hi] (1..127: all of (0, 1]) and compares with the host's libm bit for bit.
+ * n_double: arguments whose double results differ; n_float: those whose (float) -log2 differ
+ * too (first_bad = one of them).  Returns 1 when the run completed. */
+int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
+                             unsigned long long *n_double, unsigned long long *n_float,
+                             float *first_bad);
+
 #ifdef __cplusplus
 }
 #endif

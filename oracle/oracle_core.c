@@ -1113,29 +1113,88 @@ int fa_core_encode_frames(unsigned n, fa_job *jobs)
 
 const char *fa_core_name(void) { return "oracle-cpu"; }
 
-/* staged form of the seam: the CPU oracle has nothing to make resident */
-struct oracle_staged { unsigned n; fa_job *jobs; };
+/* staged form of the seam: the CPU oracle has nothing to make resident.  To behave like a
+ * device that works while the host goes on, a submitted pass remembers WHICH frames it was
+ * submitted with (the host may hand over the next ones before it collects, fa_core_upload_*)
+ * and is computed when it is collected. */
+struct oracle_staged {
+    unsigned n; fa_job *jobs;
+    const fa_image **snap;          /* frames of the submitted pass */
+    int submitted;
+    int16_t *up[2]; size_t up_bytes[2]; int up_cur;
+};
 
 void *fa_core_stage(unsigned n, fa_job *jobs)
 {
-    struct oracle_staged *s = (struct oracle_staged *) malloc(sizeof *s);
+    struct oracle_staged *s = (struct oracle_staged *) calloc(1, sizeof *s);
     s->n = n; s->jobs = jobs;
+    s->snap = (const fa_image **) calloc(n ? n : 1, sizeof *s->snap);
     return s;
 }
 
-int fa_core_run(void *h)
+static int run_snapshot(struct oracle_staged *s)
+{
+    unsigned i;
+    int good;
+    for (i = 0; i < s->n; i++) {
+        const fa_image *cur = s->jobs[i].image;
+        if (s->jobs[i].wfa->states > s->jobs[i].wfa->basis_states)
+            fa_wfa_remove_states(s->jobs[i].wfa, s->jobs[i].wfa->basis_states);
+        if (s->submitted) { s->jobs[i].image = s->snap[i]; s->snap[i] = cur; }
+    }
+    good = fa_core_encode_frames(s->n, s->jobs);
+    if (s->submitted)
+        for (i = 0; i < s->n; i++) s->jobs[i].image = s->snap[i];
+    s->submitted = 0;
+    return good;
+}
+
+int fa_core_submit(void *h)
 {
     struct oracle_staged *s = (struct oracle_staged *) h;
     unsigned i;
-    for (i = 0; i < s->n; i++)
-        if (s->jobs[i].wfa->states > s->jobs[i].wfa->basis_states)
-            fa_wfa_remove_states(s->jobs[i].wfa, s->jobs[i].wfa->basis_states);
-    return fa_core_encode_frames(s->n, s->jobs);
+    if (!s) return 0;
+    if (s->submitted) return 1;
+    for (i = 0; i < s->n; i++) s->snap[i] = s->jobs[i].image;
+    s->submitted = 1;
+    return 1;
 }
 
-void fa_core_unstage(void *h) { free(h); }
+int fa_core_finish2(void *h, int resubmit)
+{
+    struct oracle_staged *s = (struct oracle_staged *) h;
+    int good;
+    if (!s) return 0;
+    if (!s->submitted) fa_core_submit(h);
+    good = run_snapshot(s);
+    if (resubmit) fa_core_submit(h);
+    return good;
+}
 
-/* the CPU oracle has nothing to overlap: submit is a no-op, finish does the work */
-int fa_core_submit(void *h) { return h != NULL; }
-int fa_core_finish(void *h) { return fa_core_run(h); }
-int fa_core_finish2(void *h, int resubmit) { (void) resubmit; return fa_core_run(h); }
+int fa_core_finish(void *h) { return fa_core_finish2(h, 0); }
+int fa_core_run(void *h) { return fa_core_submit(h) ? fa_core_finish(h) : 0; }
+
+void fa_core_unstage(void *h)
+{
+    struct oracle_staged *s = (struct oracle_staged *) h;
+    if (s) { free(s->up[0]); free(s->up[1]); free(s->snap); }
+    free(s);
+}
+
+/* replacement inputs: plain memory, two buffers used alternately like the device's (the
+ * frames of the pass in flight must stay intact) */
+int16_t *fa_core_upload_buffer(void *h, size_t bytes)
+{
+    struct oracle_staged *s = (struct oracle_staged *) h;
+    int p;
+    if (!s) return NULL;
+    p = s->up_cur ^= 1;
+    if (bytes > s->up_bytes[p]) {
+        free(s->up[p]);
+        s->up[p] = (int16_t *) malloc(bytes);
+        s->up_bytes[p] = s->up[p] ? bytes : 0;
+    }
+    return s->up[p];
+}
+
+int fa_core_upload_commit(void *h) { return h != NULL; }

@@ -23,6 +23,10 @@ set -euo pipefail
 REF=${FIASCO_REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
 OUT=$HERE/_ref
+if [ -n "${FIASCO_SKIP_REF_BUILD:-}" ]; then
+    echo "ref_build: FIASCO_SKIP_REF_BUILD set -- not touching $OUT" >&2
+    exit 0
+fi
 if [ ! -d "$REF/codec" ]; then
     echo "ref_build: $REF not present (GPU box?) -- keeping prebuilt $OUT" >&2
     exit 0
@@ -35,6 +39,28 @@ fi
 # only the generated header is needed; the Makefiles/libtool that configure also emits are not
 # used by this recipe and are not kept
 find "$OUT/cfg" -mindepth 1 ! -name config.h -delete 2>/dev/null || true
+# The generated header must say what the pinned streams were produced with: every macro that
+# changes results, nothing else that does (oracle/ref_config.expect).
+python3 - "$OUT/cfg/config.h" "$HERE/ref_config.expect" <<'PY' || exit 1
+import re, sys
+have = dict(re.findall(r'^#define\s+(\w+)\s*(.*)$', open(sys.argv[1]).read(), re.M))
+bad = []
+for line in open(sys.argv[2]):
+    line = line.split('#')[0].split()
+    if not line:
+        continue
+    if line[0] == 'absent':
+        if line[1] in have: bad.append('%s must not be defined' % line[1])
+    elif have.get(line[0], None) is None or have[line[0]].strip() != line[1]:
+        bad.append('%s: expected %s, config.h has %r' % (line[0], line[1], have.get(line[0])))
+if bad:
+    sys.exit('ref_build: config.h differs from oracle/ref_config.expect:\n  ' + '\n  '.join(bad))
+PY
+{   # what the checker was built with (tests/golden/MANIFEST.json records the same at golden time)
+    echo "gcc: $(gcc --version | head -1)"
+    echo "config_h_sha256: $(sha256sum "$OUT/cfg/config.h" | cut -d' ' -f1)"
+    echo "flags: -O2 -g -fcommon (baseline x86-64, no FMA contraction of the sources)"
+} > "$OUT/BUILD_INFO"
 CFLAGS="-O2 -g -fcommon -fPIC -w -DHAVE_CONFIG_H -I$OUT/cfg -I$REF -I$REF/lib -I$REF/input -I$REF/output -I$REF/codec -DFIASCO_SHARE=\"$REF/data\""
 objs=()
 for f in "$REF"/lib/*.c "$REF"/input/*.c "$REF"/output/*.c "$REF"/codec/*.c; do

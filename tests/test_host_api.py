@@ -180,6 +180,39 @@ def test_submit_collect_on_oracle_seam(oracle, inputs):
     b.free()
 
 
+def check_upload_replaces_inputs(lib, inputs):
+    """fiasco_amd_batch_upload: a staged batch takes new frames of the same geometry; what the
+    next pass returns is what a fresh batch of those frames returns, pass after pass."""
+    import fiasco_amd
+    import synth
+    o = lib.cli_options()
+    sets = [[synth.pgm_bytes(synth.synth(96, 64, 10 * k + i)) for i in range(9)] for k in range(3)]
+    want = [lib.encode_batch(s, 20.0, o) for s in sets]
+    assert all(None not in w for w in want)
+    b = fiasco_amd.Batch(lib, sets[0], 20.0, o)
+    assert b.encode() == want[0]
+    b.upload(sets[1])
+    assert b.encode() == want[1]
+    # pipelined: the frames of pass i + 1 are handed over while pass i is in flight
+    b.submit()
+    b.upload(sets[2])
+    assert b.collect(resubmit=True) == want[1]
+    b.upload(sets[0])
+    assert b.collect(resubmit=True) == want[2]
+    assert b.collect() == want[0]
+    # a frame of another size is refused and the batch keeps its frames
+    bad = list(sets[1]); bad[3] = synth.pgm_bytes(synth.synth(64, 64, 1))
+    with pytest.raises(fiasco_amd.FiascoError):
+        b.upload(bad)
+    assert "size" in lib.error_message()
+    assert b.encode() == want[0]
+    b.free(); o.delete()
+
+
+def test_upload_on_oracle_seam(oracle, inputs):
+    check_upload_replaces_inputs(oracle, inputs)
+
+
 # root-range figures printed by the real reference (`cfiasco -V 2`, codec/coder.c:918-923) for
 # two committed inputs: (squared error, total costs) per band
 REFERENCE_STATS = {

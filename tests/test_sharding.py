@@ -47,3 +47,24 @@ def test_two_rank_gloo_shard_and_gather(oracle, inputs, tmp_path):
     assert all(r is not None for r in ref)
     from conftest import ORACLE_LIB
     mp.spawn(_worker, args=(2, 29531, paths, ref, ORACLE_LIB), nprocs=2, join=True)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun environment) must become a 2-rank job and print
+    ONE line with n_gpus == 2.  FIASCO_BENCH_DRYRUN=1 takes the device coder out (this container
+    has no GPU): launcher, rendezvous on 127.0.0.1, max-over-ranks timing, the reductions and the
+    gather of the per-rank streams run exactly as on the GPU box, over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FIASCO_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "0", "--frames-per-gpu", "6"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["dry_run"] is True and j["scaling"] == "weak"
+    assert j["config"]["parallelism"] == "frames x2"

@@ -113,10 +113,27 @@ int fa_setup_params(const fa_options *op, float quality, unsigned width, unsigne
     cp->check_for_underflow = op->check_for_underflow;
     cp->check_for_overflow  = op->check_for_overflow;
     cp->full_search         = op->full_search;
+    cp->prediction     = op->prediction;
+    cp->p_min_level    = wi->p_min_level;
+    cp->p_max_level    = wi->p_max_level;
+    cp->delta_domains  = op->delta_domains;
+    cp->normal_domains = op->normal_domains;
+    cp->search_range   = wi->search_range;
+    cp->half_pixel     = wi->half_pixel;
+    cp->cross_B_search = wi->cross_B_search;
     cp->price        = 128 * 64 / quality;
     cp->limit_states = g_limit_states;
     cp->limit_level  = g_limit_level;
-    if (strcasecmp(op->id_domain_pool, "rle") != 0 || strcasecmp(op->id_rpf_model, "adaptive") != 0) {
+    if (frames > 1 && op->half_pixel_prediction) {
+        /* codec/motion.c:271 divides the vector after its conversion to unsigned: every negative
+         * half-pixel component addresses memory far outside the frame.  Nothing to be bit
+         * compatible with; cfiasco cannot switch it on (bin/cwfa.c never sets video parameters) */
+        fa_set_error("Half-pixel motion vectors are not supported (the reference coder's half-pixel "
+                     "path reads outside the reference frame).");
+        return 0;
+    }
+    if (strcasecmp(op->id_domain_pool, "rle") != 0 || strcasecmp(op->id_rpf_model, "adaptive") != 0
+        || strcasecmp(op->id_d_domain_pool, "rle") != 0 || strcasecmp(op->id_d_rpf_model, "adaptive") != 0) {
         fa_set_error("Only the default `rle' domain pool and `adaptive' coefficient model are built.");
         return 0;
     }
@@ -175,17 +192,52 @@ bad:
     return NULL;
 }
 
-static int frame_is_intra(unsigned display, const char *pattern, int *ok)
+/* pattern2type, codec/coder.c:670-690; the first frame is always intra (:522-523) */
+static int frame_type_of(unsigned display, const char *pattern, int *ok)
 {
     int c = toupper((unsigned char) pattern[display % strlen(pattern)]);
     *ok = 1;
-    if (display == 0) return 1;            /* first frame is forced to be intra */
-    if (c == 'I') return 1;
-    if (c != 'P' && c != 'B') {
-        fa_set_error("Frame type %c not valid. Choose one of I,B or P.", c);
-        *ok = 0;
+    if (display == 0 || c == 'I') return FA_I_FRAME;
+    if (c == 'P') return FA_P_FRAME;
+    if (c == 'B') return FA_B_FRAME;
+    fa_set_error("Frame type %c not valid. Choose one of I,B or P.", c);
+    *ok = 0;
+    return FA_I_FRAME;
+}
+
+/* The order in which video_coder (codec/coder.c:490-668) codes the frames of a sequence and
+ * the type it gives each: a run of B frames is preceded by its future reference, which is the
+ * next non-B frame of the pattern or -- at the end of the sequence -- the last frame, coded as
+ * a P frame.  order[k] = display number of the k-th coded frame.  Returns 0 on a pattern error. */
+static int coding_order(unsigned nframes, const char *pattern, unsigned *order, int *type, int *is_future)
+{
+    unsigned display = 0, k = 0;
+    int future_display = -1, ok;
+    while (display < nframes) {
+        int t = frame_type_of(display, pattern, &ok);
+        unsigned frame;
+        if (!ok) return 0;
+        if ((int) display == future_display) { display++; continue; }
+        if (t == FA_B_FRAME && (int) display > future_display) {
+            unsigned i = display;
+            while (t == FA_B_FRAME) {
+                i++;
+                if (i >= nframes) { future_display = (int) i - 1; t = FA_P_FRAME; }
+                else {
+                    future_display = (int) i;
+                    t = frame_type_of(i, pattern, &ok);
+                    if (!ok) return 0;
+                }
+            }
+            frame = (unsigned) future_display;
+        } else {
+            frame = display;
+            display++;
+        }
+        order[k] = frame; type[k] = t; is_future[k] = (int) frame == future_display;
+        k++;
     }
-    return 0;
+    return (int) k;
 }
 
 /* ---------------------------------------------------------------- one still -> bytes */
@@ -241,6 +293,8 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     size_t *lens = NULL;
     unsigned carry_min_level;
     uint8_t *carry_ycol = NULL;
+    unsigned *order = NULL;
+    int *types = NULL, *isfut = NULL, ncoded = 0, video = 0, last_was_future = 0;
 
     memset(&wi, 0, sizeof wi);
     templ = (!inputname || !inputname[0] || strcmp(inputname[0], "-") == 0) ? default_input : inputname;
@@ -300,64 +354,104 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     if (nframes == 0) { fa_set_error("Can't open frame `%s'.", "<none>"); goto done; }
 
     if (!fa_setup_params(op, quality, w, h, color, nframes, &wi, &cp)) goto done;
-    if (op->prediction) {
-        fa_set_error("Intra prediction (ND) is not supported by this library build.");
-        goto done;
-    }
-    for (i = 0; i < nframes; i++) {
-        int ok, intra = frame_is_intra(i, op->pattern, &ok);
-        if (!ok) goto done;
-        if (!intra) {
-            fa_set_error("P/B frames (motion compensation) are not supported by this library "
-                         "build; use frame pattern `i'.");
-            goto done;
-        }
-    }
+    order = (unsigned *) calloc(nframes, sizeof *order);
+    types = (int *) calloc(nframes, sizeof *types);
+    isfut = (int *) calloc(nframes, sizeof *isfut);
+    if (!order || !types || !isfut) { fa_set_error("Out of memory!"); goto done; }
+    ncoded = coding_order(nframes, op->pattern, order, types, isfut);
+    if (ncoded <= 0) goto done;
+    for (i = 0; i < (unsigned) ncoded; i++) if (types[i] != FA_I_FRAME) video = 1;
 
     fa_bw_init(&out); have_out = 1;
     carry_min_level = cp.lc_min_level;
     carry_ycol = NULL;
-    for (i = 0; i < nframes; ) {
-        /* Gray frames are independent and go to the core as one batch; colour frames carry
-         * lc_min_level from frame to frame (codec/coder.c:785-797) and go one by one. */
-        unsigned nb = color ? 1 : nframes - i, k, good;
-        fa_job *jobs = (fa_job *) calloc(nb, sizeof *jobs);
-        fa_image **ims = (fa_image **) calloc(nb, sizeof *ims);
-        int failed = 0;
-        for (k = 0; k < nb && !failed; k++) {
-            ims[k] = fa_image_from_pnm(bufs[i + k], lens[i + k], names[i + k]);
-            if (!ims[k]) { failed = 1; break; }
-            cp.lc_min_level = carry_min_level;
-            if (!prepare_job(&jobs[k], ims[k], &cp, op->basis_name)) failed = 1;
-            else if (color && carry_ycol) {
-                /* the y_column flags the previous frame left behind (see fa_job.ycol_carry) */
-                memcpy(jobs[k].wfa->y_column, carry_ycol, (size_t) jobs[k].wfa->cap * 2);
-                jobs[k].ycol_carry = 1;
-            }
+    if (!video && !color) {
+        /* Gray all-intra frames are independent and go to the core as one batch. */
+        fa_job *jobs = (fa_job *) calloc(nframes, sizeof *jobs);
+        fa_image **ims = (fa_image **) calloc(nframes, sizeof *ims);
+        unsigned k, good;
+        int failed = !jobs || !ims;
+        if (failed) fa_set_error("Out of memory!");
+        for (k = 0; k < nframes && !failed; k++) {
+            ims[k] = fa_image_from_pnm(bufs[k], lens[k], names[k]);
+            if (!ims[k] || !prepare_job(&jobs[k], ims[k], &cp, op->basis_name)) failed = 1;
         }
         if (!failed) {
-            good = (unsigned) fa_core_encode_frames(nb, jobs);
-            if (good != nb) {
-                for (k = 0; k < nb; k++)
+            good = (unsigned) fa_core_encode_frames(nframes, jobs);
+            if (good != nframes) {
+                for (k = 0; k < nframes; k++)
                     if (!jobs[k].status) { fa_set_error("%s", jobs[k].errmsg); break; }
                 failed = 1;
             }
         }
-        for (k = 0; k < nb && !failed; k++) {
+        for (k = 0; k < nframes && !failed; k++) {
             report(&jobs[k], &wi);
-            if (!fa_write_frame(jobs[k].wfa, &wi, FA_I_FRAME, i + k, 0, op->normal_domains,
+            if (!fa_write_frame(jobs[k].wfa, &wi, FA_I_FRAME, k, op->prediction, op->normal_domains,
                                 op->delta_domains, &out))
                 failed = 1;
-            carry_min_level = jobs[k].lc_min_level_out;
-            if (color) {
-                if (!carry_ycol) carry_ycol = (uint8_t *) malloc((size_t) jobs[k].wfa->cap * 2);
-                if (carry_ycol) memcpy(carry_ycol, jobs[k].wfa->y_column, (size_t) jobs[k].wfa->cap * 2);
-            }
         }
-        for (k = 0; k < nb; k++) { fa_wfa_free(jobs[k].wfa); fa_image_free(ims[k]); }
+        for (k = 0; jobs && ims && k < nframes; k++) { fa_wfa_free(jobs[k].wfa); fa_image_free(ims[k]); }
         free(jobs); free(ims);
         if (failed) goto done;
-        i += nb;
+    } else {
+        /* video_coder (codec/coder.c:490-668): the frames one after the other in coding order.
+         * Colour frames carry lc_min_level from frame to frame (:785-797); a P/B frame is
+         * predicted from the RECONSTRUCTED frames before it (:580-651). */
+        fa_image *reconst = NULL, *past = NULL, *future = NULL;
+        int failed = 0;
+        for (i = 0; i < (unsigned) ncoded && !failed; i++) {
+            const unsigned frame = order[i];
+            const int type = types[i];
+            fa_job job;
+            fa_image *im;
+            if (type == FA_I_FRAME) {
+                fa_image_free(past); fa_image_free(future); fa_image_free(reconst);
+                past = future = reconst = NULL;
+            } else if (type == FA_P_FRAME) {
+                fa_image_free(past); past = reconst; reconst = NULL;
+                fa_image_free(future); future = NULL;
+            } else if (last_was_future) {
+                fa_image_free(future); future = reconst; reconst = NULL;
+            } else if (wi.B_as_past_ref) {
+                fa_image_free(past); past = reconst; reconst = NULL;
+            } else {
+                fa_image_free(reconst); reconst = NULL;
+            }
+            last_was_future = isfut[i];
+            im = fa_image_from_pnm(bufs[frame], lens[frame], names[frame]);
+            if (!im) { failed = 1; break; }
+            cp.lc_min_level = carry_min_level;
+            if (!prepare_job(&job, im, &cp, op->basis_name)) { fa_wfa_free(job.wfa); fa_image_free(im); failed = 1; break; }
+            job.frame_type = type; job.past = past; job.future = future;
+            if (color && carry_ycol) {
+                /* the y_column flags the previous frame left behind (see fa_job.ycol_carry) */
+                memcpy(job.wfa->y_column, carry_ycol, (size_t) job.wfa->cap * 2);
+                job.ycol_carry = 1;
+            }
+            if (fa_core_encode_frames(1, &job) != 1) { fa_set_error("%s", job.errmsg); failed = 1; }
+            if (!failed) {
+                report(&job, &wi);
+                if (!fa_write_frame(job.wfa, &wi, type, frame, op->prediction, op->normal_domains,
+                                    op->delta_domains, &out))
+                    failed = 1;
+            }
+            if (!failed) {
+                carry_min_level = job.lc_min_level_out;
+                if (color) {
+                    if (!carry_ycol) carry_ycol = (uint8_t *) malloc((size_t) job.wfa->cap * 2);
+                    if (carry_ycol) memcpy(carry_ycol, job.wfa->y_column, (size_t) job.wfa->cap * 2);
+                }
+                if (video && i + 1 < (unsigned) ncoded) {      /* reference for the frames to come */
+                    reconst = fa_decode_image(wi.width, wi.height, job.wfa, color);
+                    if (!reconst || (type != FA_I_FRAME
+                                     && !fa_restore_mc(reconst, past, future, job.wfa, wi.p_max_level)))
+                        failed = 1;
+                }
+            }
+            fa_wfa_free(job.wfa); fa_image_free(im);
+        }
+        fa_image_free(reconst); fa_image_free(past); fa_image_free(future);
+        if (failed || i < (unsigned) ncoded) goto done;
     }
     {
         size_t nbytes = fa_bw_finish(&out);
@@ -368,6 +462,7 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     }
     rc = 1;
 done:
+    free(order); free(types); free(isfut);
     free(carry_ycol);
     if (have_out) fa_bw_free(&out);
     if (fout && fout != stdout) fclose(fout);
@@ -388,7 +483,7 @@ struct fiasco_amd_batch {
     fa_image **prev_ims;      /* frames of the pass before the last upload: a pass that was
                                * submitted with them may still be in flight */
     fa_info   *infos;
-    int        normal_domains, delta_domains;
+    int        normal_domains, delta_domains, prediction;
     void      *staged;        /* core handle: inputs resident where the core computes */
 };
 
@@ -431,11 +526,6 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
     if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return NULL; }
     if (options) { op = fa_cast_options(options); if (!op) return NULL; }
     else { defaults = fiasco_c_options_new(); if (!defaults) return NULL; op = fa_cast_options(defaults); }
-    if (op->prediction) {
-        fa_set_error("Intra prediction (ND) is not supported by this library build.");
-        if (defaults) fiasco_c_options_delete(defaults);
-        return NULL;
-    }
     b = (fiasco_amd_batch_t *) calloc(1, sizeof *b);
     if (b) {
         b->jobs  = (fa_job *) calloc(n ? n : 1, sizeof *b->jobs);
@@ -451,6 +541,7 @@ fiasco_amd_batch_t *fiasco_amd_batch_stage(unsigned n, const unsigned char *cons
     b->n = n;
     b->normal_domains = op->normal_domains;
     b->delta_domains  = op->delta_domains;
+    b->prediction     = op->prediction;
     for (i = 0; i < n; i++) {
         fa_cparams cp;
         b->ims[i] = fa_image_from_pnm(pnm[i], pnm_len[i], "<memory>");
@@ -505,7 +596,7 @@ static void *wr_thread(void *arg)
         if (!b->jobs[i].status) continue;
         if (b->n == 1) dump_wfa(b->jobs[i].wfa);
         fa_bw_init(&out);
-        if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, 0, b->normal_domains,
+        if (fa_write_frame(b->jobs[i].wfa, &b->infos[i], FA_I_FRAME, 0, b->prediction, b->normal_domains,
                            b->delta_domains, &out)) {
             w->out_len[i] = fa_bw_finish(&out);
             w->outv[i] = (unsigned char *) malloc(w->out_len[i]);

@@ -99,9 +99,16 @@ fa_image *fa_image_from_pnm_into(const unsigned char *buf, size_t len, const cha
 int       fa_pnm_header(const unsigned char *buf, size_t len, const char *name,
                         unsigned *w, unsigned *h, int *color, size_t *data_off);
 void      fa_image_free(fa_image *im);
+fa_image *fa_image_alloc(unsigned width, unsigned height, int color);   /* zeroed planes */
+
+/* ---------------- reconstruction (reference codec/decoder.c, codec/motion.c) ------- */
 unsigned char *fa_read_whole_file(const char *name, const char *env_var, size_t *len);
 
 /* ---------------- automaton container handed to the writer ---------------- */
+/* motion vector of a (state, label): reference codec/wfa.h:43-63 mv_t */
+enum { FA_MV_NONE = 0, FA_MV_FORWARD = 1, FA_MV_BACKWARD = 2, FA_MV_INTERPOLATED = 3 };
+typedef struct fa_mv { int16_t type, fx, fy, bx, by; } fa_mv;
+
 typedef struct fa_wfa {
     unsigned cap;                 /* allocated states */
     unsigned states, basis_states, root_state;
@@ -117,6 +124,7 @@ typedef struct fa_wfa {
     int16_t *y_state;             /* [cap][2] */
     uint8_t *y_column;            /* [cap][2] */
     uint8_t *prediction;          /* [cap][2] */
+    fa_mv   *mv;                  /* [cap][2] mv_tree */
 } fa_wfa;
 #define FA_TREE(w, s, l)      ((w)->tree[(s) * 2 + (l)])
 #define FA_INTO(w, s, l, e)   ((w)->into[((s) * 2 + (l)) * 6 + (e)])
@@ -124,8 +132,20 @@ typedef struct fa_wfa {
 fa_wfa *fa_wfa_alloc(unsigned cap);
 void    fa_wfa_free(fa_wfa *w);
 void    fa_wfa_remove_states(fa_wfa *w, unsigned from);
-void    fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, unsigned label);
+int     fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, unsigned label);
+                                  /* 0: the label already has FA_MAXEDGES edges */
 int     fa_load_basis(const char *name, fa_wfa *w);   /* 1 ok / 0 error */
+
+/* the frame an automaton describes, 4:4:4, cropped to the coded size (decode_image,
+ * codec/decoder.c:411-536); NULL + message on failure */
+fa_image *fa_decode_image(unsigned orig_width, unsigned orig_height, const fa_wfa *w, int color);
+/* add the motion compensation of a P/B frame (restore_mc, codec/motion.c:37-229) */
+int       fa_restore_mc(fa_image *image, const fa_image *past, const fa_image *future,
+                        const fa_wfa *w, unsigned p_max_level);
+void      fa_extract_mc_block(int16_t *mcblock, unsigned width, unsigned height,
+                              const int16_t *reference, unsigned ref_width,
+                              unsigned xo, unsigned yo, int mx, int my);
+double    fa_plane_mse(const int16_t *a, const int16_t *b, size_t n);
 
 /* ---------------- stream info (reference codec/wfa.h:65-110 wfa_info_t) ----------- */
 typedef struct fa_info {
@@ -152,6 +172,12 @@ typedef struct fa_cparams {
     int      second_domain_block, check_for_underflow, check_for_overflow, full_search;
     unsigned level;                       /* bintree level of the whole image */
     unsigned limit_states, limit_level;   /* MAXSTATES / MAXLEVEL in force */
+    /* prediction (codec/prediction.c) and motion compensation (codec/mwfa.c) */
+    int      prediction;                  /* options.prediction: intra (ND) prediction */
+    unsigned p_min_level, p_max_level;    /* wi->p_min_level / p_max_level */
+    int      delta_domains, normal_domains;
+    unsigned search_range;
+    int      half_pixel, cross_B_search;
 } fa_cparams;
 
 /* result statistics of one coded band (root range), used for -V 2 style reporting */
@@ -161,6 +187,8 @@ typedef struct fa_stats {
 
 typedef struct fa_job {
     const fa_image   *image;      /* in  */
+    int               frame_type; /* in: FA_I_FRAME / FA_P_FRAME / FA_B_FRAME */
+    const fa_image   *past, *future;   /* in: reconstructed reference frames of a P/B frame */
     fa_cparams        cp;         /* in  (lc_min_level may be ratcheted: colour) */
     fa_wfa           *wfa;        /* in: basis states loaded; out: finished automaton */
     fa_stats          stats[3];   /* out */

@@ -28,7 +28,8 @@ fa_wfa *fa_wfa_alloc(unsigned cap)
     w->y_state    = (int16_t *)  calloc((size_t) cap * 2, sizeof(int16_t));
     w->y_column   = (uint8_t *)  calloc((size_t) cap * 2, 1);
     w->prediction = (uint8_t *)  calloc((size_t) cap * 2, 1);
-    if (!w->final_distribution || !w->level_of_state || !w->domain_type || !w->delta_state
+    w->mv         = (fa_mv *)    calloc((size_t) cap * 2, sizeof(fa_mv));
+    if (!w->mv || !w->final_distribution || !w->level_of_state || !w->domain_type || !w->delta_state
         || !w->tree || !w->x || !w->y || !w->into || !w->weight || !w->y_state
         || !w->y_column || !w->prediction) {
         fa_wfa_free(w);
@@ -50,7 +51,7 @@ void fa_wfa_free(fa_wfa *w)
     if (!w) return;
     free(w->final_distribution); free(w->level_of_state); free(w->domain_type);
     free(w->delta_state); free(w->tree); free(w->x); free(w->y); free(w->into);
-    free(w->weight); free(w->y_state); free(w->y_column); free(w->prediction);
+    free(w->weight); free(w->y_state); free(w->y_column); free(w->prediction); free(w->mv);
     free(w);
 }
 
@@ -63,6 +64,7 @@ void fa_wfa_remove_states(fa_wfa *w, unsigned from)
             FA_TREE(w, s, l)         = FA_RANGE;
             w->prediction[s * 2 + l] = 0;
             w->y_state[s * 2 + l]    = FA_RANGE;
+            memset(&w->mv[s * 2 + l], 0, sizeof(fa_mv));      /* type NONE, zero vectors */
         }
         w->domain_type[s] = 0;
         w->delta_state[s] = 0;
@@ -70,19 +72,21 @@ void fa_wfa_remove_states(fa_wfa *w, unsigned from)
     w->states = from;
 }
 
-void fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, unsigned label)
+int fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, unsigned label)
 {
     int pos = 0, last, e;
     while (FA_INTO(w, from, label, pos) != FA_NO_EDGE && FA_INTO(w, from, label, pos) < (int) into)
         pos++;
     for (last = pos; FA_INTO(w, from, label, last) != FA_NO_EDGE; last++)
         ;
+    if (last >= FA_MAXEDGES) return 0;          /* the row holds MAXEDGES edges + the terminator */
     for (e = last + 1; e > pos; e--) {          /* shift tail incl. the terminator */
         FA_INTO(w, from, label, e)   = FA_INTO(w, from, label, e - 1);
         FA_WEIGHT(w, from, label, e) = FA_WEIGHT(w, from, label, e - 1);
     }
     FA_INTO(w, from, label, pos)   = (int16_t) into;
     FA_WEIGHT(w, from, label, pos) = weight;
+    return 1;
 }
 
 /* ------------------------------------------------------------------ basis */
@@ -140,6 +144,7 @@ static int ascii_basis(const char *name, fa_wfa *w)
     FILE *f = open_file(name, "FIASCO_DATA", READ_ACCESS);
     char tok[64];
     unsigned s, n;
+    long nl;
     if (!f) { fa_set_error("File `%s': I/O Error - %s.", name, "No such file or directory"); return 0; }
 #define NEED_TOKEN() do { if (!next_token(f, tok, sizeof tok)) goto bad; } while (0)
     NEED_TOKEN();
@@ -149,8 +154,9 @@ static int ascii_basis(const char *name, fa_wfa *w)
         return 0;
     }
     NEED_TOKEN();
-    n = (unsigned) atoi(tok);
-    if (n + 1 >= w->cap) goto bad;
+    nl = strtol(tok, NULL, 10);                 /* states besides state 0 */
+    if (nl <= 0 || nl + 1 >= (long) w->cap) goto bad;
+    n = (unsigned) nl;
     w->basis_states = w->states = n + 1;
     basis_state0(w);
     for (s = 1; s <= n; s++) { NEED_TOKEN(); w->domain_type[s] = atoi(tok) ? FA_USE_DOMAIN : FA_AUXILIARY; }
@@ -166,7 +172,7 @@ static int ascii_basis(const char *name, fa_wfa *w)
             NEED_TOKEN(); dom = atoi(tok);
             NEED_TOKEN(); wt = strtof(tok, NULL);
             if (label < 0 || label > 1 || dom < 0 || dom > (int) n) goto bad;
-            fa_wfa_append_edge(w, s, (unsigned) dom, wt, (unsigned) label);
+            if (!fa_wfa_append_edge(w, s, (unsigned) dom, wt, (unsigned) label)) goto bad;
         }
     }
     fclose(f);

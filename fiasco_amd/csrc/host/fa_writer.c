@@ -9,8 +9,8 @@
  *                                                chroma QAC columns)
  *    weights          output/weights.c:37-200   + lib/arith.c:196-306 (encode_array)
  *    interval rescale lib/arith.h:93-119
- *  ND / MC sections (output/nd.c, output/mc.c) are not produced: intra prediction and
- *  P/B frames are outside this round's scope and rejected before coding starts.
+ *    nd               output/nd.c:49-242        (prediction tree + DC weights of predicted ranges)
+ *    mc               output/mc.c:76-251        (motion tree VLC + MPEG vector codes)
  */
 #include <stdlib.h>
 #include <string.h>
@@ -305,7 +305,8 @@ static unsigned delta_encoding(int use_normal, int use_delta, const fa_wfa *wfa,
         for (r = 0; r < rs.n; r++)
             if (!rs.subdivided[r]) {
                 unsigned s = rs.state[r], l = rs.label[r], last = 1, e;
-                const uint16_t *map = wfa->delta_state[s] ? map2 : map1;  /* mv type is NONE */
+                const uint16_t *map = (wfa->delta_state[s] || wfa->mv[s * 2 + l].type != FA_MV_NONE)
+                                      ? map2 : map1;               /* output/matrices.c:226-230 */
                 unsigned max_value = map[rs.max_domain[r]];
                 int dom;
                 for (e = 0; (dom = FA_INTO(wfa, s, l, e)) != FA_NO_EDGE; e++)
@@ -372,17 +373,23 @@ static void encode_array(fa_bitw *out, const unsigned *data, const unsigned *con
     if (!n_context) n_context = 1;
     totals = (uint16_t **) calloc(n_context, sizeof *totals);
     for (c = 0; c < n_context; c++) {
-        totals[c] = (uint16_t *) calloc(c_symbols[c] + 1, sizeof(uint16_t));
+        /* one element in front of the table: the symbol may be RPF_ZERO = -1 (a leaf range that
+         * is motion compensated but does not belong to a delta state is written in the NORMAL
+         * format although the coder quantised it in the delta format, output/weights.c:140-170;
+         * a weight too small for the normal format then has no symbol).  The reference reads
+         * totals[-1] -- with glibc the upper half of the chunk header, 0 -- and goes on
+         * (lib/arith.c:252-260, `int d`); so does this. */
+        totals[c] = (uint16_t *) calloc(c_symbols[c] + 2, sizeof(uint16_t)) + 1;
         for (i = 0; i < c_symbols[c]; i++) totals[c][i + 1] = (uint16_t) (totals[c][i] + 1);
     }
     ac_init(&a, out);
     for (n = 0; n < n_data; n++) {
-        unsigned d = data[n];
+        int d = (int) data[n];
         uint16_t *t;
         c = n_context > 1 ? context[n] : 0;
         t = totals[c];
         ac_encode(&a, t[d], t[d + 1], t[c_symbols[c]]);
-        for (i = d + 1; i < c_symbols[c] + 1; i++) t[i]++;
+        for (i = (unsigned) (d + 1); i < c_symbols[c] + 1; i++) t[i]++;
         if (t[c_symbols[c]] > scaling)
             for (i = 1; i < c_symbols[c] + 1; i++) {
                 t[i] >>= 1;
@@ -390,7 +397,7 @@ static void encode_array(fa_bitw *out, const unsigned *data, const unsigned *con
             }
     }
     ac_flush(&a);
-    for (c = 0; c < n_context; c++) free(totals[c]);
+    for (c = 0; c < n_context; c++) free(totals[c] - 1);
     free(totals);
 }
 
@@ -478,8 +485,141 @@ static void locate_delta_images(fa_wfa *wfa)
     for (state = (int) wfa->root_state; state >= (int) wfa->basis_states; state--)
         for (label = 0; label < 2; label++)
             if (FA_TREE(wfa, state, label) != FA_RANGE)
-                if (FA_INTO(wfa, state, label, 0) != FA_NO_EDGE || wfa->delta_state[state])
+                if (wfa->mv[state * 2 + label].type != FA_MV_NONE
+                    || FA_INTO(wfa, state, label, 0) != FA_NO_EDGE || wfa->delta_state[state])
                     wfa->delta_state[FA_TREE(wfa, state, label)] = 1;
+}
+
+/* ------------------------------------------------------------ prediction (output/nd.c) */
+
+/* encode_nd_tree :65-177: breadth first, one binary decision per child between p_min_level and
+ * p_max_level ("the child's range is predicted": the (state,label) carries edges as well);
+ * adaptive binary coder, counts halved above 50.  Returns the number of predicted ranges. */
+static unsigned write_nd_tree(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out)
+{
+    unsigned *queue = (unsigned *) malloc(sizeof(unsigned) * (wfa->states + 1));
+    unsigned head = 0, tail = 0, used = 0, label;
+    unsigned sum0 = 1, sum1 = 11;
+    ac16 a;
+    if (!queue) return 0;
+    ac_init(&a, out);
+    queue[tail++] = wfa->root_state;
+    while (head < tail) {
+        const unsigned next = queue[head++];
+        if (wfa->level_of_state[next] > wi->p_max_level + 1) {
+            for (label = 0; label < 2; label++)
+                if (FA_TREE(wfa, next, label) != FA_RANGE) queue[tail++] = (unsigned) FA_TREE(wfa, next, label);
+        } else if (wfa->level_of_state[next] > wi->p_min_level) {
+            for (label = 0; label < 2; label++) {
+                const int child = FA_TREE(wfa, next, label);
+                unsigned range;
+                if (child == FA_RANGE) continue;
+                range = (unsigned) (a.high - a.low) + 1;
+                if (FA_INTO(wfa, next, label, 0) != FA_NO_EDGE) {       /* prediction used: '1' */
+                    used++;
+                    a.low = (uint16_t) (a.low + (uint16_t) ((range * sum0) / sum1));
+                    ac_rescale(&a);
+                } else {                                                 /* '0': go on below */
+                    if (wfa->level_of_state[child] > wi->p_min_level) queue[tail++] = (unsigned) child;
+                    a.high = (uint16_t) (a.low + (uint16_t) ((range * sum0) / sum1 - 1));
+                    ac_rescale(&a);
+                    sum0 = (uint16_t) (sum0 + 1);
+                }
+                sum1 = (uint16_t) (sum1 + 1);
+                if (sum1 > 50) {
+                    sum0 >>= 1; sum1 >>= 1;
+                    if (!sum0) sum0 = 1;
+                    if (sum0 >= sum1) sum1 = sum0 + 1;
+                }
+            }
+        }
+    }
+    ac_flush(&a);
+    free(queue);
+    return used;
+}
+
+/* encode_nd_coefficients :179-242: the weights of every edge on a (state,label) that has a tree
+ * child too, DC format, one adaptive context (scale 50) */
+static int write_nd(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out)
+{
+    unsigned total = write_nd_tree(wfa, wi, out), n = 0, state, label, e;
+    unsigned *coeff, c_symbols = 1u << (wi->dc_rpf.mantissa_bits + 1);
+    if (!total) return 1;
+    coeff = (unsigned *) calloc(total, sizeof(unsigned));
+    if (!coeff) { fa_set_error("Out of memory!"); return 0; }
+    for (state = wfa->basis_states; state < wfa->states; state++)
+        for (label = 0; label < 2; label++)
+            if (FA_TREE(wfa, state, label) != FA_RANGE && FA_INTO(wfa, state, label, 0) != FA_NO_EDGE)
+                for (e = 0; FA_INTO(wfa, state, label, e) != FA_NO_EDGE; e++) {
+                    if (n >= total) {
+                        fa_set_error("Can't write more than %d coefficients.", (int) total);
+                        free(coeff);
+                        return 0;
+                    }
+                    coeff[n++] = (unsigned) fa_rtob(FA_WEIGHT(wfa, state, label, e), &wi->dc_rpf);
+                }
+    encode_array(out, coeff, NULL, &c_symbols, 1, total, 50);
+    free(coeff);
+    return 1;
+}
+
+/* ------------------------------------------------------------ motion compensation (output/mc.c) */
+
+/* MPEG's Huffman code of a vector component: {code, length}, index = component + search range
+ * (codec/mwfa.c:40-50) */
+static const unsigned short mv_code[33][2] = {
+    {0x19, 11}, {0x1b, 11}, {0x1d, 11}, {0x1f, 11}, {0x21, 11}, {0x23, 11}, {0x13, 10}, {0x15, 10},
+    {0x17, 10}, {0x7, 8}, {0x9, 8}, {0xb, 8}, {0x7, 7}, {0x3, 5}, {0x3, 4}, {0x3, 3}, {0x1, 1},
+    {0x2, 3}, {0x2, 4}, {0x2, 5}, {0x6, 7}, {0xa, 8}, {0x8, 8}, {0x6, 8}, {0x16, 10}, {0x14, 10},
+    {0x12, 10}, {0x22, 11}, {0x20, 11}, {0x1e, 11}, {0x1c, 11}, {0x1a, 11}, {0x18, 11} };
+
+static void put_mv(fa_bitw *out, int v, unsigned sr)
+{
+    fa_bw_put_bits(out, mv_code[v + (int) sr][0], mv_code[v + (int) sr][1]);
+}
+
+static int write_mc(int frame_type, const fa_wfa *wfa, const fa_info *wi, fa_bitw *out)
+{
+    /* NONE, FORWARD, BACKWARD, INTERPOLATED: P frames 1 / 0, B frames 1 / 000 / 001 / 01 (:36-53) */
+    static const unsigned char pcode[4][2] = { {1, 1}, {0, 1}, {0, 0}, {0, 0} };
+    static const unsigned char bcode[4][2] = { {1, 1}, {0, 3}, {1, 3}, {1, 2} };
+    const unsigned char (*code)[2] = frame_type == FA_P_FRAME ? pcode : bcode;
+    const unsigned max_state = wi->color ? (unsigned) FA_TREE(wfa, (unsigned) FA_TREE(wfa, wfa->root_state, 0), 0)
+                                         : wfa->states;
+    unsigned *queue = (unsigned *) malloc(sizeof(unsigned) * (wfa->states + 1));
+    unsigned last = 0, cur, state, label;
+    if (!queue) { fa_set_error("Out of memory!"); return 0; }
+    /* motion tree, breadth first from the states of level p_max_level (:76-146) */
+    for (state = wfa->basis_states; state < max_state; state++)
+        if ((int) wfa->level_of_state[state] - 1 == (int) wi->p_max_level) queue[last++] = state;
+    for (cur = 0; cur < last; cur++)
+        for (label = 0; label < 2; label++) {
+            const unsigned lv = (unsigned) wfa->level_of_state[queue[cur]] - 1;
+            unsigned type;
+            state = queue[cur];
+            type = (unsigned) wfa->mv[state * 2 + label].type;
+            if (wfa->x[state * 2 + label] + fa_width_of_level(lv) <= wi->width
+                && wfa->y[state * 2 + label] + fa_height_of_level(lv) <= wi->height)
+                fa_bw_put_bits(out, code[type][0], code[type][1]);
+            if (type == FA_MV_NONE && FA_TREE(wfa, state, label) != FA_RANGE && lv >= wi->p_min_level)
+                queue[last++] = (unsigned) FA_TREE(wfa, state, label);
+        }
+    fa_bw_align(out);
+    free(queue);
+    /* vector components in state order (:148-251) */
+    for (state = wfa->basis_states; state < max_state; state++)
+        for (label = 0; label < 2; label++) {
+            const fa_mv *mv = &wfa->mv[state * 2 + label];
+            if (mv->type == FA_MV_FORWARD || mv->type == FA_MV_INTERPOLATED) {
+                put_mv(out, mv->fx, wi->search_range); put_mv(out, mv->fy, wi->search_range);
+            }
+            if (mv->type == FA_MV_BACKWARD || mv->type == FA_MV_INTERPOLATED) {
+                put_mv(out, mv->bx, wi->search_range); put_mv(out, mv->by, wi->search_range);
+            }
+        }
+    fa_bw_align(out);
+    return 1;
 }
 
 int fa_write_frame(const fa_wfa *wfa_in, const fa_info *wi, int frame_type, unsigned number,
@@ -498,10 +638,8 @@ int fa_write_frame(const fa_wfa *wfa_in, const fa_info *wi, int frame_type, unsi
     fa_bw_align(out);
     if (!write_tree(wfa, out)) return 0;
     fa_bw_put_bit(out, prediction ? 1u : 0u);
-    if (prediction || frame_type != FA_I_FRAME) {
-        fa_set_error("ND/MC stream sections are not supported by this library build.");
-        return 0;
-    }
+    if (prediction && !write_nd(wfa, wi, out)) return 0;
+    if (frame_type != FA_I_FRAME && !write_mc(frame_type, wfa, wi, out)) return 0;
     root_state = wi->color
         ? (unsigned) FA_TREE(wfa, (unsigned) FA_TREE(wfa, wfa->root_state, 0), 0)
         : wfa->root_state;

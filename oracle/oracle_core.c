@@ -37,13 +37,40 @@ typedef struct rle_model {
     uint16_t d0_n;          /* 0 or 1 */
 } rle_model;
 
-typedef struct range {
+typedef struct range {                  /* codec/cwfa.h:46-75 */
     unsigned x, y, image, address, level, global_address;
     float    weight[MAXED + 1];
     int16_t  into[MAXED + 1];
     int      tree;
     float    err, tree_bits, matrix_bits, weights_bits;
+    fa_mv    mv;
+    float    mv_tree_bits, mv_coord_bits, nd_tree_bits, nd_weights_bits;
+    int      prediction;
 } range;
+
+/* a domain pool: the "rle" model or the model-free "constant" pool {state 0}
+ * (codec/domain-pool.c:504-544, 621-879) */
+typedef struct pool {
+    int       constant;
+    rle_model m;
+    int16_t  *states;       /* states[] of the lineage (see rle_model) */
+} pool;
+
+/* "adaptive" coefficient model (codec/coeff.c:190-326): counts per context, int16 */
+typedef struct cmodel {
+    int16_t      *cnt, *tot;
+    const fa_rpf *rpf, *dc_rpf;
+    unsigned      size, nt;
+} cmodel;
+
+/* motion_t (codec/cwfa.h:26-44): reference frames and the per-level displacement cost tables */
+typedef struct motion {
+    int             frame_type;
+    const fa_image *past, *future;
+    float          *fwd[FA_CAP_LEVEL + 2], *bwd[FA_CAP_LEVEL + 2];
+    float           xbits[64];        /* == ybits: code lengths of the MPEG vector code */
+    unsigned        range_size;
+} motion;
 
 typedef struct mpres {
     int16_t exclude[MAXED];
@@ -66,11 +93,16 @@ typedef struct oc {
     float   *pixels;                    /* 2^lc_max pixels of the current block, tree order  */
     unsigned ML;                        /* MAXLEVEL in force                                 */
     unsigned *tm;                       /* tree models: counts,total,p_counts,p_total [4*ML] */
-    rle_model pool;
-    int16_t  *pool_states;              /* shared states[] of the pool lineage */
-    int16_t  *coeff;                    /* aac counts: [dc symbols][level][symbols] */
-    int16_t  *coeff_totals;             /* [1 + levels] */
-    unsigned  coeff_min, coeff_max, coeff_size, coeff_nt;
+    pool      pl[2];                    /* domain_pool, d_domain_pool */
+    cmodel    cm[2];                    /* coeff, d_coeff */
+    int16_t  *cbuf;                     /* counts + totals of both models, one block */
+    size_t    cbuf_n;
+    unsigned  coeff_min, coeff_max;
+    float    *ipis_alt;                 /* second <sub-block, state> table: prediction residuals */
+    int16_t  *planes[3];                /* pixels of the frame being coded (chroma: private copy
+                                         * once the luminance motion is subtracted) */
+    motion    mt;
+    unsigned  p_min, p_max;
     float     m0[1024], m1[1024];       /* qac bit tables */
     /* matching-pursuit scratch, indexed by POSITION in the domain list */
     float    *rem_num, *rem_den, *ipdo; /* ipdo[d*MAXED + k] */
@@ -156,38 +188,45 @@ static void init_matrix_tables(oc *c)
     for (; idx < 1024; idx++) c->m0[idx] = c->m1[idx] = 0;
 }
 
-/* ------------------------------------------------------------------ rle pool (domain-pool.c:621-879) */
+/* ------------------------------------------------------------------ domain pools (domain-pool.c) */
 
-static void pool_init(oc *c)
+/* alloc_rle_domain_pool / alloc_const_domain_pool (:504-516, 632-676) */
+static void pool_init(oc *c, pool *pl, int constant)
 {
     unsigned m, s;
-    memset(&c->pool, 0, sizeof c->pool);
-    for (m = 0; m < MAXED + 1; m++) { c->pool.count[m] = 1; c->pool.total++; }
-    c->pool.max_domains = (uint16_t) c->cp->pool_max_states;
+    memset(&pl->m, 0, sizeof pl->m);
+    pl->constant = constant;
+    if (constant) return;
+    for (m = 0; m < MAXED + 1; m++) { pl->m.count[m] = 1; pl->m.total++; }
+    pl->m.max_domains = (uint16_t) c->cp->pool_max_states;
     for (s = 0; s < c->w->basis_states; s++)
         if (usedomain(c->w, (int) s)) {
-            if (c->pool.n < c->pool.max_domains) {
-                c->pool_states[c->pool.n++] = (int16_t) s;
-                if (s == 0) { c->pool.d0_index = 0; c->pool.d0_n = 1; }
+            if (pl->m.n < pl->m.max_domains) {
+                pl->states[pl->m.n++] = (int16_t) s;
+                if (s == 0) { pl->m.d0_index = 0; pl->m.d0_n = 1; }
             }
         }
 }
 
-static int pool_append(oc *c, unsigned state)
+/* ->append: rle_append :832-852, default_append :957-962 (the constant pool takes everything) */
+static int pool_append(pool *pl, unsigned state)
 {
-    if (c->pool.n >= c->pool.max_domains) return 0;
-    c->pool_states[c->pool.n++] = (int16_t) state;
+    if (pl->constant) return 1;
+    if (pl->m.n >= pl->m.max_domains) return 0;
+    pl->states[pl->m.n++] = (int16_t) state;
     return 1;
 }
 
 /* -1 terminated candidate list: the pool states plus the co-located Y state if usable
- * and not already present (rle_generate :707-735).  Returns the list length. */
-static unsigned pool_generate(oc *c, int y_state, int16_t *out)
+ * and not already present (rle_generate :707-735); the constant pool is {0} (:518-528).
+ * Returns the list length. */
+static unsigned pool_generate(oc *c, const pool *pl, int y_state, int16_t *out)
 {
-    unsigned n, len = c->pool.n;
+    unsigned n, len = pl->m.n;
     int present = 0;
+    if (pl->constant) { out[0] = 0; out[1] = -1; return 1; }
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
-    memcpy(out, c->pool_states, len * sizeof(int16_t));
+    memcpy(out, pl->states, len * sizeof(int16_t));
     for (n = 0; n < len; n++) if (out[n] == y_state) present = 1;
     if (!present && y_state >= 0) out[len++] = (int16_t) y_state;
     out[len] = -1;
@@ -215,13 +254,15 @@ static float d0_bits(const oc *c, const rle_model *m, int y_state, int uses0)
     return b;
 }
 
-/* rle_bits :737-793.  `used` = -1 terminated list of POSITIONS in `domains`, or NULL. */
-static float pool_bits(const oc *c, const int16_t *domains, const int16_t *used, int y_state)
+/* rle_bits :737-793, const_bits :530-536.  `used` = -1 terminated list of POSITIONS in
+ * `domains`, or NULL. */
+static float pool_bits(const oc *c, const pool *pl, const int16_t *domains, const int16_t *used, int y_state)
 {
-    const rle_model *m = &c->pool;
+    const rle_model *m = &pl->m;
     int16_t sorted[MAXED + 1];
     unsigned n = 0, e, last;
     float bits;
+    if (pl->constant) return 0;
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
     if (used) {
         for (e = 0; used[e] != FA_NO_EDGE; e++)
@@ -246,12 +287,13 @@ static float pool_bits(const oc *c, const int16_t *domains, const int16_t *used,
     return bits;
 }
 
-/* rle_update :795-830 with the nested qac_update :404-446 */
-static void pool_update(oc *c, const int16_t *domains, const int16_t *used, int y_state)
+/* rle_update :795-830 with the nested qac_update :404-446; default_update for the constant pool */
+static void pool_update(oc *c, pool *pl, const int16_t *domains, const int16_t *used, int y_state)
 {
-    rle_model *m = &c->pool;
+    rle_model *m = &pl->m;
     int state_0 = 0, state_y = 0;
     unsigned edge = 0;
+    if (pl->constant) return;
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
     if (used)
         for (edge = 0; used[edge] != FA_NO_EDGE; edge++) {
@@ -275,15 +317,17 @@ static void pool_update(oc *c, const int16_t *domains, const int16_t *used, int 
     if (m->y_index > 1020) m->y_index = 1020;
 }
 
-/* rle_chroma :854-879 */
+/* rle_chroma :854-879 (only the normal pool is asked, codec/coder.c:779) */
 static void pool_chroma(oc *c)
 {
-    rle_model *m = &c->pool;
+    pool *pl = &c->pl[0];
+    rle_model *m = &pl->m;
     unsigned maxd = c->cp->chroma_max_states;
+    if (pl->constant) return;
     if (maxd < m->n) {
         int16_t *dom = fa_compute_hits(c->w->basis_states, c->w->states - 1, maxd, c->w);
         unsigned n;
-        for (n = 0; n < maxd && dom[n] >= 0; n++) c->pool_states[n] = dom[n];
+        for (n = 0; n < maxd && dom[n] >= 0; n++) pl->states[n] = dom[n];
         if (n < maxd) maxd = n;
         free(dom);
         m->n = (uint16_t) maxd;
@@ -296,49 +340,66 @@ static void pool_chroma(oc *c)
 
 static void coeff_init(oc *c)
 {
-    unsigned dcs = 1u << (1 + c->cp->dc_rpf.mantissa_bits), sy = 1u << (1 + c->cp->rpf.mantissa_bits);
-    unsigned i;
+    const fa_rpf *rp[2][2] = { { &c->cp->rpf, &c->cp->dc_rpf }, { &c->cp->d_rpf, &c->cp->d_dc_rpf } };
+    unsigned k, i, levels;
+    size_t off = 0;
     c->coeff_min = c->lc_min; c->coeff_max = c->lc_max;
-    c->coeff_size = (c->coeff_max - c->coeff_min + 1) * sy + dcs;
-    c->coeff_nt = c->coeff_max - c->coeff_min + 2;
-    c->coeff = (int16_t *) malloc(c->coeff_size * sizeof(int16_t));
-    c->coeff_totals = (int16_t *) malloc(c->coeff_nt * sizeof(int16_t));
-    for (i = 0; i < c->coeff_size; i++) c->coeff[i] = 1;
-    c->coeff_totals[0] = (int16_t) dcs;
-    for (i = 1; i < c->coeff_nt; i++) c->coeff_totals[i] = (int16_t) sy;
+    levels = c->coeff_max - c->coeff_min + 1;
+    for (k = 0; k < 2; k++) {
+        c->cm[k].rpf = rp[k][0]; c->cm[k].dc_rpf = rp[k][1];
+        c->cm[k].size = levels * (1u << (1 + rp[k][0]->mantissa_bits)) + (1u << (1 + rp[k][1]->mantissa_bits));
+        c->cm[k].nt = levels + 1;
+        off += c->cm[k].size + c->cm[k].nt;
+    }
+    c->cbuf_n = off;
+    c->cbuf = (int16_t *) malloc(off * sizeof(int16_t));
+    off = 0;
+    for (k = 0; k < 2; k++) {
+        cmodel *m = &c->cm[k];
+        m->cnt = c->cbuf + off; off += m->size;
+        m->tot = c->cbuf + off; off += m->nt;
+        for (i = 0; i < m->size; i++) m->cnt[i] = 1;
+        m->tot[0] = (int16_t) (1u << (1 + m->dc_rpf->mantissa_bits));
+        for (i = 1; i < m->nt; i++) m->tot[i] = (int16_t) (1u << (1 + m->rpf->mantissa_bits));
+    }
 }
 
-static int16_t *coeff_ctx(const oc *c, unsigned level)
+static int16_t *coeff_ctx(const oc *c, const cmodel *m, unsigned level)
 {
-    return c->coeff + (1u << (1 + c->cp->dc_rpf.mantissa_bits))
-           + (level - c->coeff_min) * (1u << (1 + c->cp->rpf.mantissa_bits));
+    return m->cnt + (1u << (1 + m->dc_rpf->mantissa_bits))
+           + (level - c->coeff_min) * (1u << (1 + m->rpf->mantissa_bits));
 }
 
-static float coeff_bits(const oc *c, const float *wt, const int16_t *states, unsigned level)
+/* aac_bits :215-240.  A weight that quantises to RPF_ZERO indexes counts[-1]: in a level
+ * context that is the last symbol of the context in front; in the DC context it lies in front
+ * of the reference's array -- with glibc the upper half of the chunk header, 0, i.e. +inf bits */
+static float coeff_bits(const oc *c, const cmodel *m, const float *wt, const int16_t *states, unsigned level)
 {
     float bits = 0;
-    const int16_t *ctx = coeff_ctx(c, level);
+    const int16_t *ctx = coeff_ctx(c, m, level);
     unsigned e;
     for (e = 0; states[e] != FA_NO_EDGE; e++)
         if (states[e])
-            bits -= log2(ctx[fa_rtob(wt[e], &c->cp->rpf)]
-                         / (float) c->coeff_totals[level - c->coeff_min + 1]);
-        else
-            bits -= log2(c->coeff[fa_rtob(wt[e], &c->cp->dc_rpf)] / (float) c->coeff_totals[0]);
+            bits -= log2(ctx[fa_rtob(wt[e], m->rpf)] / (float) m->tot[level - c->coeff_min + 1]);
+        else {
+            int sym = fa_rtob(wt[e], m->dc_rpf);
+            bits -= log2((sym < 0 ? 0 : m->cnt[sym]) / (float) m->tot[0]);
+        }
     return bits;
 }
 
-static void coeff_update(oc *c, const float *wt, const int16_t *states, unsigned level)
+static void coeff_update(oc *c, cmodel *m, const float *wt, const int16_t *states, unsigned level)
 {
-    int16_t *ctx = coeff_ctx(c, level);
+    int16_t *ctx = coeff_ctx(c, m, level);
     unsigned e;
     for (e = 0; states[e] != FA_NO_EDGE; e++)
         if (states[e]) {
-            ctx[fa_rtob(wt[e], &c->cp->rpf)]++;
-            c->coeff_totals[level - c->coeff_min + 1]++;
+            ctx[fa_rtob(wt[e], m->rpf)]++;
+            m->tot[level - c->coeff_min + 1]++;
         } else {
-            c->coeff[fa_rtob(wt[e], &c->cp->dc_rpf)]++;
-            c->coeff_totals[0]++;
+            int sym = fa_rtob(wt[e], m->dc_rpf);
+            if (sym >= 0) m->cnt[sym]++;
+            m->tot[0]++;
         }
 }
 
@@ -579,7 +640,7 @@ static void orthogonalize(oc *c, unsigned index, unsigned n, unsigned level, con
 /* approx.c:317-642 (the <v_l,o_n> refresh :554-569 feeds only itself and is omitted,
  * SURVEY §7.3 "dead code that looks live"; :570-571 are kept) */
 static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, unsigned max_edges,
-                             int y_state, const range *rg)
+                             int y_state, const range *rg, const pool *pl, const cmodel *cm)
 {
     const float min_norm = 2e-3f;
     int16_t *dl = c->dlist;
@@ -587,7 +648,7 @@ static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, uns
     int index;
     float norm, additional_bits;
 
-    pool_generate(c, y_state, dl);
+    pool_generate(c, pl, y_state, dl);
     for (d = 0; dl[d] >= 0; d++) {
         c->used[d] = 0;
         c->rem_den[d] = ip_state_state(c, (unsigned) dl[d], (unsigned) dl[d], rg->level);
@@ -603,11 +664,12 @@ static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, uns
         float p = c->pixels[(size_t) rg->address * size + n];
         norm += p * p;
     }
-    additional_bits = rg->tree_bits;      /* mv / nd terms are zero without prediction */
+    additional_bits = rg->tree_bits + rg->mv_tree_bits + rg->mv_coord_bits + rg->nd_tree_bits
+                      + rg->nd_weights_bits;                          /* approx.c:391-393 */
 
     mp->err = norm;
     mp->weights_bits = 0;
-    mp->matrix_bits = pool_bits(c, dl, NULL, y_state);
+    mp->matrix_bits = pool_bits(c, pl, dl, NULL, y_state);
     mp->costs = (mp->matrix_bits + mp->weights_bits + additional_bits) * price + mp->err;
 
     n = 0;
@@ -631,8 +693,8 @@ static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, uns
                     }
                 vectors[i] = (int16_t) d; states[i] = dl[d]; weights[i] = 0.5f;
                 vectors[i + 1] = -1; states[i + 1] = -1;
-                weights_bits = coeff_bits(c, weights, states, rg->level);
-                matrix_bits  = pool_bits(c, dl, vectors, y_state);
+                weights_bits = coeff_bits(c, cm, weights, states, rg->level);
+                matrix_bits  = pool_bits(c, pl, dl, vectors, y_state);
             }
             if (((matrix_bits + weights_bits + additional_bits) * price + mp->err
                  - c->rem_num[d] * c->rem_num[d] / c->rem_den[d]) < min_costs) {
@@ -648,7 +710,7 @@ static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, uns
                     v[k] = mp->indices[k];
                 }
                 for (l = (int) n; l >= 0; l--) {      /* back substitution, rounding each step */
-                    const fa_rpf *rpf = dl[v[l]] ? &c->cp->rpf : &c->cp->dc_rpf;
+                    const fa_rpf *rpf = dl[v[l]] ? cm->rpf : cm->dc_rpf;
                     r[l] = f[l] = quant(f[l], rpf);
                     for (k = 0; k < (unsigned) l; k++)
                         f[k] -= f[l] * c->ipdo[v[l] * MAXED + k] / c->norm_ov[k];
@@ -665,8 +727,8 @@ static void matching_pursuit(oc *c, mpres *mp, int full_search, float price, uns
                             i++;
                         }
                     vectors[i] = -1; states[i] = -1;
-                    w_bits = coeff_bits(c, weights, states, rg->level);
-                    m_bits = pool_bits(c, dl, vectors, y_state);
+                    w_bits = coeff_bits(c, cm, weights, states, rg->level);
+                    m_bits = pool_bits(c, pl, dl, vectors, y_state);
                 }
                 c->norm_ov[n] = c->rem_den[d];
                 c->ipio[n]    = c->rem_num[d];
@@ -716,18 +778,18 @@ static int is_extreme(float wgt, const fa_rpf *rpf)
 
 /* approx.c:74-271 */
 static float approximate_range(oc *c, float max_costs, float price, unsigned max_edges,
-                               int y_state, range *rg)
+                               int y_state, range *rg, pool *pl, cmodel *cm)
 {
     mpres mp;
     memset(&mp, 0, sizeof mp);
     mp.exclude[0] = FA_NO_EDGE;
-    matching_pursuit(c, &mp, c->cp->full_search, price, max_edges, y_state, rg);
+    matching_pursuit(c, &mp, c->cp->full_search, price, max_edges, y_state, rg, pl, cm);
 
     if (c->cp->second_domain_block) {
         mpres t = mp;
         t.exclude[0] = t.indices[0];
         t.exclude[1] = FA_NO_EDGE;
-        matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+        matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg, pl, cm);
         if (t.costs < mp.costs) mp = t;
     }
     if (c->cp->check_for_underflow) {
@@ -741,7 +803,7 @@ static float approximate_range(oc *c, float max_costs, float price, unsigned max
                 if (t.weight[i] == 0) { t.exclude[it] = t.indices[i]; break; }
             if (t.exclude[it] != FA_NO_EDGE) {
                 t.exclude[it + 1] = FA_NO_EDGE;
-                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg, pl, cm);
                 if (t.costs < mp.costs) mp = t;
             }
         } while (t.exclude[it] != FA_NO_EDGE && it < MAXED - 1);
@@ -754,12 +816,12 @@ static float approximate_range(oc *c, float max_costs, float price, unsigned max
             it++;
             t.exclude[it] = FA_NO_EDGE;
             for (i = 0; t.indices[i] != FA_NO_EDGE; i++) {
-                const fa_rpf *rpf = t.indices[i] ? &c->cp->rpf : &c->cp->dc_rpf;
+                const fa_rpf *rpf = t.indices[i] ? cm->rpf : cm->dc_rpf;
                 if (is_extreme(t.weight[i], rpf)) { t.exclude[it] = t.indices[i]; break; }
             }
             if (t.exclude[it] != FA_NO_EDGE) {
                 t.exclude[it + 1] = FA_NO_EDGE;
-                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg);
+                matching_pursuit(c, &t, c->cp->full_search, price, max_edges, y_state, rg, pl, cm);
                 if (t.costs < mp.costs) mp = t;
             }
         } while (t.exclude[it] != FA_NO_EDGE && it < MAXED - 1);
@@ -776,9 +838,9 @@ static float approximate_range(oc *c, float max_costs, float price, unsigned max
             }
         mp.indices[ni] = FA_NO_EDGE;
         mp.into[ni]    = FA_NO_EDGE;
-        pool_generate(c, y_state, c->dlist);
-        pool_update(c, c->dlist, mp.indices, y_state);
-        coeff_update(c, mp.weight, mp.into, rg->level);
+        pool_generate(c, pl, y_state, c->dlist);
+        pool_update(c, pl, c->dlist, mp.indices, y_state);
+        coeff_update(c, cm, mp.weight, mp.into, rg->level);
         for (e = 0; mp.indices[e] != FA_NO_EDGE; e++) {
             rg->into[e]   = mp.into[e];
             rg->weight[e] = mp.weight[e];
@@ -797,7 +859,7 @@ static float approximate_range(oc *c, float max_costs, float price, unsigned max
         int e;
         memset(&t, 0, sizeof t);
         t.seq = c->trace_n++; t.level = (int) rg->level; t.image = (int) rg->image;
-        t.D = (int) c->pool.n; t.states = (int) c->w->states;
+        t.D = (int) (pl->constant ? 1 : pl->m.n); t.states = (int) c->w->states;
         t.cost = mp.costs; t.err = mp.err; t.mbits = mp.matrix_bits; t.wbits = mp.weights_bits;
         for (e = 0; e < 6; e++) t.into[e] = -1;
         for (e = 0; mp.costs < FA_MAXCOSTS && rg->into[e] != FA_NO_EDGE; e++) { t.into[e] = rg->into[e]; t.w[e] = rg->weight[e]; }
@@ -828,25 +890,24 @@ static void init_range(oc *c, range *rg, unsigned band)
     unsigned s;
     for (s = 0; s < c->w->states; s++)
         if (need_image(c->w, s)) memset(ipis_of(c, s), 0, c->nprod * sizeof(float));
-    cut_to_bintree(c->pixels, c->im->pixels[band], c->im->width, c->im->height, rg->x, rg->y,
+    cut_to_bintree(c->pixels, c->planes[band], c->im->width, c->im->height, rg->x, rg->y,
                    fa_width_of_level(rg->level), fa_height_of_level(rg->level));
     rg->address = rg->image = 0;
     compute_ip_images_state(c, 0, 0, rg->level, 1, 0);
 }
 
 /* subdivide.c:549-610 */
-static void init_new_state(oc *c, int auxiliary, range *rg, const range *child, const int *y_state)
+static void init_new_state(oc *c, int auxiliary, int delta, range *rg, const range *child, const int *y_state)
 {
     fa_wfa *w = c->w;
     unsigned label, s = w->states;
     int is_domain = 0;
-    /* codec/subdivide.c:571-581: the state is offered to the rle pool (which may be full)
-     * and, because normal_domains is set, to the delta pool as well.  For I frames without
-     * prediction the delta pool is "constant", whose append() is default_append() == YES
-     * (domain-pool.c:957-962), so every non-auxiliary state keeps its image tables. */
+    /* :571-581: a state that is not auxiliary is offered to the normal pool (unless it is a
+     * delta state and delta_domains is off) and to the delta pool (if it is a delta state or
+     * normal_domains is on); it keeps its image tables when either pool takes it */
     if (!auxiliary) {
-        (void) pool_append(c, s);
-        is_domain = 1;
+        if (!delta || c->cp->delta_domains) is_domain = pool_append(&c->pl[0], s);
+        if (delta || c->cp->normal_domains) is_domain = pool_append(&c->pl[1], s) || is_domain;
     }
     rg->into[0] = FA_NO_EDGE;
     rg->tree = (int) s;
@@ -854,40 +915,553 @@ static void init_new_state(oc *c, int auxiliary, range *rg, const range *child, 
         unsigned e;
         FA_TREE(w, s, label) = (int16_t) child[label].tree;
         w->y_state[s * 2 + label] = (int16_t) y_state[label];
+        w->mv[s * 2 + label] = child[label].mv;
         w->x[s * 2 + label] = (uint16_t) child[label].x;
         w->y[s * 2 + label] = (uint16_t) child[label].y;
-        w->prediction[s * 2 + label] = 0;
+        w->prediction[s * 2 + label] = (uint8_t) child[label].prediction;
         w->y_column[s * 2 + label] = 0;
         for (e = 0; child[label].into[e] != FA_NO_EDGE; e++) {
             fa_wfa_append_edge(w, s, (unsigned) child[label].into[e], child[label].weight[e], label);
             if (child[label].into[e] == w->y_state[s * 2 + label]) w->y_column[s * 2 + label] = 1;
         }
     }
-    w->delta_state[s] = 0;
+    w->delta_state[s] = (uint8_t) delta;
     append_state(c, !is_domain, final_distribution(w, s), rg->level);
 }
 
 static float fminf2(float a, float b) { return a > b ? b : a; }
 
-/* subdivide.c:60-502 without the prediction branch */
-static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range *rg)
+/* ------------------------------------------------------------------ motion search (codec/mwfa.c) */
+
+/* MPEG's vector-component code lengths (mv_code_table[][1], codec/mwfa.c:40-50) */
+static const uint8_t mv_code_bits[33] = { 11, 11, 11, 11, 11, 11, 10, 10, 10, 8, 8, 8, 7, 5, 4, 3, 1,
+                                          3, 4, 5, 7, 8, 8, 8, 10, 10, 10, 11, 11, 11, 11, 11, 11 };
+
+static unsigned mt_sr(const oc *c) { return c->cp->search_range; }      /* full-pixel vectors only */
+
+/* squared norm of original block - reference block (/16 per pixel, sequential float sum):
+ * get_mcpe + mcpe_norm, codec/mwfa.c:610-684.  mc2 != NULL: interpolated prediction. */
+static float mcpe_norm(const oc *c, unsigned x0, unsigned y0, unsigned width, unsigned height,
+                       const int16_t *mc1, const int16_t *mc2)
+{
+    const int16_t *o = c->planes[0] + (size_t) y0 * c->im->width + x0;
+    float norm = 0;
+    unsigned x, y;
+    for (y = 0; y < height; y++, o += c->im->width)
+        for (x = 0; x < width; x++) {
+            int16_t d = mc2 ? (int16_t) (o[x] - (mc1[y * width + x] + mc2[y * width + x]) / 2)
+                            : (int16_t) (o[x] - mc1[y * width + x]);
+            int q = d / 16;
+            norm += (float) (q * q);
+        }
+    return norm;
+}
+
+static void get_mcpe(const oc *c, int16_t *mcpe, unsigned x0, unsigned y0, unsigned width, unsigned height,
+                     const int16_t *mc1, const int16_t *mc2)
+{
+    const int16_t *o = c->planes[0] + (size_t) y0 * c->im->width + x0;
+    unsigned x, y;
+    for (y = 0; y < height; y++, o += c->im->width)
+        for (x = 0; x < width; x++)
+            *mcpe++ = mc2 ? (int16_t) (o[x] - (mc1[y * width + x] + mc2[y * width + x]) / 2)
+                          : (int16_t) (o[x] - mc1[y * width + x]);
+}
+
+/* fill_norms_table, codec/mwfa.c:545-602 */
+static void fill_norms_table(oc *c, unsigned x0, unsigned y0, unsigned level)
+{
+    const int sr = (int) mt_sr(c);
+    const unsigned width = fa_width_of_level(level), height = fa_height_of_level(level);
+    int16_t *blk = (int16_t *) malloc((size_t) width * height * sizeof(int16_t));
+    unsigned index = 0;
+    int mx, my;
+    if (!c->mt.past || (c->mt.frame_type == FA_B_FRAME && !c->mt.future)) {
+        /* e.g. an I frame as the future reference of a B frame: the reference coder dereferences
+         * a null frame at the first motion search */
+        fail(c, "Motion search without a reference frame (frame pattern).");
+        free(blk);
+        return;
+    }
+    for (my = -sr; my < sr; my++)
+        for (mx = -sr; mx < sr; mx++, index++) {
+            if ((int) x0 + mx < 0 || x0 + mx + width > c->im->width
+                || (int) y0 + my < 0 || y0 + my + height > c->im->height) {
+                c->mt.fwd[level][index] = 0.0f;
+                c->mt.bwd[level][index] = 0.0f;
+            } else {
+                fa_extract_mc_block(blk, width, height, c->mt.past->pixels[0], c->mt.past->width, x0, y0, mx, my);
+                c->mt.fwd[level][index] = mcpe_norm(c, x0, y0, width, height, blk, NULL);
+                if (c->mt.frame_type == FA_B_FRAME) {
+                    fa_extract_mc_block(blk, width, height, c->mt.future->pixels[0], c->mt.future->width,
+                                        x0, y0, mx, my);
+                    c->mt.bwd[level][index] = mcpe_norm(c, x0, y0, width, height, blk, NULL);
+                }
+            }
+        }
+    free(blk);
+}
+
+/* clear_norms_table / update_norms_table, codec/prediction.c:210-254 */
+static void clear_norms_table(oc *c, unsigned level)
+{
+    if (level > c->p_min) {
+        memset(c->mt.fwd[level], 0, c->mt.range_size * sizeof(float));
+        memset(c->mt.bwd[level], 0, c->mt.range_size * sizeof(float));
+    }
+}
+
+static void update_norms_table(oc *c, unsigned level)
+{
+    unsigned i;
+    if (level > c->p_min) {
+        for (i = 0; i < c->mt.range_size; i++) c->mt.fwd[level][i] += c->mt.fwd[level - 1][i];
+        if (c->mt.frame_type == FA_B_FRAME)
+            for (i = 0; i < c->mt.range_size; i++) c->mt.bwd[level][i] += c->mt.bwd[level - 1][i];
+    }
+}
+
+/* find_best_mv, codec/mwfa.c:686-798 (full pixel) */
+static float find_best_mv(const oc *c, float price, unsigned x0, unsigned y0, unsigned width, unsigned height,
+                          float *bits, int *mx, int *my, const float *norms)
+{
+    const int sr = (int) mt_sr(c);
+    float mincosts = FA_MAXCOSTS;
+    unsigned index = 0;
+    int x, y;
+    *mx = *my = 0;
+    for (y = -sr; y < sr; y++)
+        for (x = -sr; x < sr; x++, index++)
+            if ((int) x0 + x >= 0 && (int) y0 + y >= 0 && x0 + x + width <= c->im->width
+                && y0 + y + height <= c->im->height) {
+                float costs = norms[index] + (c->mt.xbits[x + sr] + c->mt.xbits[y + sr]) * price;
+                if (costs < mincosts) { mincosts = costs; *mx = x; *my = y; }
+            }
+    *bits = c->mt.xbits[*mx + sr] + c->mt.xbits[*my + sr];
+    return mincosts;
+}
+
+/* find_P_frame_mc, codec/mwfa.c:302-340 */
+static void find_P_frame_mc(oc *c, int16_t *mcpe, float price, range *rg)
+{
+    const unsigned width = fa_width_of_level(rg->level), height = fa_height_of_level(rg->level);
+    int16_t *blk = (int16_t *) malloc((size_t) width * height * sizeof(int16_t));
+    int fx, fy;
+    rg->mv_tree_bits = 1;
+    rg->mv.type = FA_MV_FORWARD;
+    find_best_mv(c, price, rg->x, rg->y, width, height, &rg->mv_coord_bits, &fx, &fy, c->mt.fwd[rg->level]);
+    rg->mv.fx = (int16_t) fx; rg->mv.fy = (int16_t) fy;
+    fa_extract_mc_block(blk, width, height, c->mt.past->pixels[0], c->mt.past->width, rg->x, rg->y, fx, fy);
+    get_mcpe(c, mcpe, rg->x, rg->y, width, height, blk, NULL);
+    free(blk);
+}
+
+/* find_B_frame_mc, codec/mwfa.c:342-543; cross_B_search is always off here: the reference sets
+ * it from half_pixel_prediction (codec/coder.c:359) and half-pixel vectors are refused */
+static void find_B_frame_mc(oc *c, int16_t *mcpe, float price, range *rg)
+{
+    const unsigned width = fa_width_of_level(rg->level), height = fa_height_of_level(rg->level);
+    int16_t *b1 = (int16_t *) malloc((size_t) width * height * sizeof(int16_t));
+    int16_t *b2 = (int16_t *) malloc((size_t) width * height * sizeof(int16_t));
+    float forward_costs, backward_costs, interp_costs, forward_bits, backward_bits, interp_bits;
+    int fx, fy, bx, by, type;
+    forward_costs = find_best_mv(c, price, rg->x, rg->y, width, height, &forward_bits, &fx, &fy,
+                                 c->mt.fwd[rg->level]) + 3 * price;
+    backward_costs = find_best_mv(c, price, rg->x, rg->y, width, height, &backward_bits, &bx, &by,
+                                  c->mt.bwd[rg->level]) + 3 * price;
+    interp_bits = forward_bits + backward_bits;
+    fa_extract_mc_block(b1, width, height, c->mt.past->pixels[0], c->mt.past->width, rg->x, rg->y, fx, fy);
+    fa_extract_mc_block(b2, width, height, c->mt.future->pixels[0], c->mt.future->width, rg->x, rg->y, bx, by);
+    interp_costs = mcpe_norm(c, rg->x, rg->y, width, height, b1, b2) + (interp_bits + 2) * price;
+    if (forward_costs <= interp_costs) type = forward_costs <= backward_costs ? FA_MV_FORWARD : FA_MV_BACKWARD;
+    else type = backward_costs <= interp_costs ? FA_MV_BACKWARD : FA_MV_INTERPOLATED;
+    rg->mv.type = (int16_t) type;
+    if (type == FA_MV_FORWARD) {
+        rg->mv_tree_bits = 3; rg->mv_coord_bits = forward_bits;
+        rg->mv.fx = (int16_t) fx; rg->mv.fy = (int16_t) fy;
+        get_mcpe(c, mcpe, rg->x, rg->y, width, height, b1, NULL);
+    } else if (type == FA_MV_BACKWARD) {
+        rg->mv_tree_bits = 3; rg->mv_coord_bits = backward_bits;
+        rg->mv.bx = (int16_t) bx; rg->mv.by = (int16_t) by;
+        get_mcpe(c, mcpe, rg->x, rg->y, width, height, b2, NULL);
+    } else {
+        rg->mv_tree_bits = 2; rg->mv_coord_bits = interp_bits;
+        rg->mv.fx = (int16_t) fx; rg->mv.fy = (int16_t) fy;
+        rg->mv.bx = (int16_t) bx; rg->mv.by = (int16_t) by;
+        get_mcpe(c, mcpe, rg->x, rg->y, width, height, b1, b2);
+    }
+    free(b1); free(b2);
+}
+
+/* subtract_mc, codec/mwfa.c:156-300: the luminance band's motion compensation, with the vector
+ * components rounded to even, is taken off the chroma planes before they are coded */
+static void subtract_mc(oc *c)
+{
+    const fa_wfa *w = c->w;
+    unsigned state, label, band;
+    int16_t *b1 = (int16_t *) malloc(fa_size_of_level(c->p_max) * sizeof(int16_t));
+    int16_t *b2 = (int16_t *) malloc(fa_size_of_level(c->p_max) * sizeof(int16_t));
+    for (state = w->basis_states; state < w->states; state++)
+        for (label = 0; label < 2; label++) {
+            const fa_mv *mv = &w->mv[state * 2 + label];
+            const unsigned lv = (unsigned) w->level_of_state[state] - 1;
+            const unsigned width = fa_width_of_level(lv), height = fa_height_of_level(lv);
+            const unsigned x0 = w->x[state * 2 + label], y0 = w->y[state * 2 + label];
+            if (mv->type == FA_MV_NONE) continue;
+            for (band = 1; band < 3; band++) {
+                int16_t *o = c->planes[band] + (size_t) y0 * c->im->width + x0;
+                unsigned x, y;
+                if (mv->type != FA_MV_BACKWARD)
+                    fa_extract_mc_block(b1, width, height, c->mt.past->pixels[band], c->mt.past->width, x0, y0,
+                                        (mv->fx / 2) * 2, (mv->fy / 2) * 2);
+                if (mv->type != FA_MV_FORWARD)
+                    fa_extract_mc_block(mv->type == FA_MV_BACKWARD ? b1 : b2, width, height,
+                                        c->mt.future->pixels[band], c->mt.future->width, x0, y0,
+                                        (mv->bx / 2) * 2, (mv->by / 2) * 2);
+                for (y = 0; y < height; y++, o += c->im->width)
+                    for (x = 0; x < width; x++)
+                        o[x] = (int16_t) (o[x] - (mv->type == FA_MV_INTERPOLATED
+                                                  ? (b1[y * width + x] + b2[y * width + x]) / 2 : b1[y * width + x]));
+            }
+        }
+    free(b1); free(b2);
+}
+
+/* ------------------------------------------------------------------ prediction (codec/prediction.c) */
+
+static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range *rg, int prediction, int delta);
+
+/* what store_state_data keeps of a state (codec/prediction.c:47-69, 502-565) */
+typedef struct state_data {
+    float   final_distribution;
+    uint8_t level_of_state, domain_type;
+    float  *images, *ipis, *gram;
+    int16_t tree[2], y_state[2], into[2][MAXED + 1];
+    uint8_t y_column[2], prediction[2];
+    fa_mv   mv[2];
+    uint16_t x[2], y[2];
+    float   weight[2][MAXED + 1];
+} state_data;
+
+static state_data *store_state_data(oc *c, unsigned from, unsigned to)
+{
+    fa_wfa *w = c->w;
+    state_data *data;
+    unsigned s, l;
+    if (to + 1 <= from) return NULL;
+    data = (state_data *) calloc(to - from + 1, sizeof *data);
+    for (s = from; s <= to; s++) {
+        state_data *sd = &data[s - from];
+        sd->final_distribution = w->final_distribution[s];
+        sd->level_of_state = w->level_of_state[s];
+        sd->domain_type = w->domain_type[s];
+        /* the reference moves the table pointers; the tables here are rows of flat arrays */
+        sd->images = (float *) malloc(c->nimg * sizeof(float));
+        sd->ipis = (float *) malloc(c->nprod * sizeof(float));
+        memcpy(sd->images, img_of(c, s), c->nimg * sizeof(float));
+        memcpy(sd->ipis, ipis_of(c, s), c->nprod * sizeof(float));
+        sd->gram = c->gram[s]; c->gram[s] = NULL;
+        w->domain_type[s] = 0;
+        for (l = 0; l < 2; l++) {
+            sd->tree[l] = FA_TREE(w, s, l);
+            sd->y_state[l] = w->y_state[s * 2 + l];
+            sd->y_column[l] = w->y_column[s * 2 + l];
+            sd->mv[l] = w->mv[s * 2 + l];
+            sd->x[l] = w->x[s * 2 + l]; sd->y[l] = w->y[s * 2 + l];
+            sd->prediction[l] = w->prediction[s * 2 + l];
+            memcpy(sd->weight[l], &FA_WEIGHT(w, s, l, 0), sizeof sd->weight[l]);
+            memcpy(sd->into[l], &FA_INTO(w, s, l, 0), sizeof sd->into[l]);
+            FA_INTO(w, s, l, 0) = FA_NO_EDGE;
+            FA_TREE(w, s, l) = FA_RANGE;
+            w->y_state[s * 2 + l] = FA_RANGE;
+        }
+    }
+    return data;
+}
+
+static void free_state_data(state_data *data, unsigned n)
+{
+    unsigned i;
+    for (i = 0; i < n; i++) { free(data[i].images); free(data[i].ipis); free(data[i].gram); }
+    free(data);
+}
+
+static void restore_state_data(oc *c, unsigned from, unsigned to, state_data *data)
+{
+    fa_wfa *w = c->w;
+    unsigned s, l;
+    if (to + 1 <= from) return;
+    for (s = from; s <= to; s++) {
+        state_data *sd = &data[s - from];
+        w->final_distribution[s] = sd->final_distribution;
+        w->level_of_state[s] = sd->level_of_state;
+        w->domain_type[s] = sd->domain_type;
+        memcpy(img_of(c, s), sd->images, c->nimg * sizeof(float));
+        memcpy(ipis_of(c, s), sd->ipis, c->nprod * sizeof(float));
+        free(c->gram[s]); c->gram[s] = sd->gram; sd->gram = NULL;
+        for (l = 0; l < 2; l++) {
+            FA_TREE(w, s, l) = sd->tree[l];
+            w->y_state[s * 2 + l] = sd->y_state[l];
+            w->y_column[s * 2 + l] = sd->y_column[l];
+            w->mv[s * 2 + l] = sd->mv[l];
+            w->x[s * 2 + l] = sd->x[l]; w->y[s * 2 + l] = sd->y[l];
+            w->prediction[s * 2 + l] = sd->prediction[l];
+            memcpy(&FA_WEIGHT(w, s, l, 0), sd->weight[l], sizeof sd->weight[l]);
+            memcpy(&FA_INTO(w, s, l, 0), sd->into[l], sizeof sd->into[l]);
+        }
+    }
+    free_state_data(data, to - from + 1);
+    w->states = to + 1;
+}
+
+/* the residual of a predicted range is searched with fresh <sub-block, state> tables: the
+ * reference swaps the per-state table pointers of the states that exist (prediction.c:302-309,
+ * 443-450), here the second flat table takes their place.  Returns the table to go back to. */
+static float *residual_tables_begin(oc *c, unsigned last_state)
+{
+    float *keep = c->ipis;
+    c->ipis = c->ipis_alt;
+    c->ipis_alt = keep;
+    memset(c->ipis, 0, (size_t) (last_state + 1) * c->nprod * sizeof(float));
+    return keep;
+}
+
+/* back to the tables of the block; `used`: the states appended meanwhile stay (their tables
+ * are zeroed, :342-345, 481-484) */
+static void residual_tables_end(oc *c, float *keep, unsigned last_state, int used)
+{
+    unsigned s;
+    c->ipis_alt = c->ipis;
+    c->ipis = keep;
+    if (used)
+        for (s = last_state + 1; s < c->w->states; s++)
+            if (need_image(c->w, s)) memset(ipis_of(c, s), 0, c->nprod * sizeof(float));
+}
+
+static float range_costs(const range *rg, float price)
+{
+    return (rg->tree_bits + rg->matrix_bits + rg->weights_bits + rg->mv_tree_bits + rg->mv_coord_bits
+            + rg->nd_tree_bits + rg->nd_weights_bits) * price + rg->err;
+}
+
+/* mc_prediction, codec/prediction.c:262-369 */
+static float mc_prediction(oc *c, float max_costs, float price, unsigned band, int y_state, range *rg)
+{
+    range prange = *rg;
+    const unsigned width = fa_width_of_level(rg->level), height = fa_height_of_level(rg->level);
+    int16_t *mcpe = (int16_t *) calloc((size_t) width * height, sizeof(int16_t));
+    float costs;
+
+    if (prange.level == c->p_min) fill_norms_table(c, prange.x, prange.y, prange.level);
+    if (!c->mt.past || (c->mt.frame_type == FA_B_FRAME && !c->mt.future))
+        fail(c, "Motion search without a reference frame (frame pattern).");
+    if (c->failed) { free(mcpe); return FA_MAXCOSTS; }
+    if (c->mt.frame_type == FA_P_FRAME) find_P_frame_mc(c, mcpe, price, &prange);
+    else find_B_frame_mc(c, mcpe, price, &prange);
+    costs = (prange.mv_tree_bits + prange.mv_coord_bits) * price;
+    if (costs < max_costs) {
+        float *block_pixels = c->pixels, *tables;
+        const unsigned last_state = c->w->states - 1;
+        const float mvc = prange.mv_coord_bits, mvt = prange.mv_tree_bits;
+        c->pixels = (float *) calloc(fa_size_of_level(c->lc_max), sizeof(float));
+        cut_to_bintree(c->pixels, mcpe, width, height, 0, 0, width, height);
+        tables = residual_tables_begin(c, last_state);
+        prange.image = 0; prange.address = 0;
+        prange.tree_bits = prange.matrix_bits = prange.weights_bits = 0;
+        prange.mv_coord_bits = prange.mv_tree_bits = 0;
+        prange.nd_weights_bits = prange.nd_tree_bits = 0;
+        compute_ip_images_state(c, prange.image, prange.address, prange.level, 1, 0);
+        costs += subdivide(c, max_costs - costs, band, y_state, &prange, 0, 1);
+        if (costs < max_costs) {
+            const unsigned img = rg->image, adr = rg->address;
+            *rg = prange;
+            rg->image = img; rg->address = adr;
+            rg->mv_coord_bits = mvc; rg->mv_tree_bits = mvt;
+            rg->prediction = 1;
+            residual_tables_end(c, tables, last_state, 1);
+            costs = range_costs(rg, price);
+        } else {
+            residual_tables_end(c, tables, last_state, 0);
+            costs = FA_MAXCOSTS;
+        }
+        free(c->pixels);
+        c->pixels = block_pixels;
+    } else
+        costs = FA_MAXCOSTS;
+    free(mcpe);
+    return costs;
+}
+
+/* nd_prediction, codec/prediction.c:371-500 */
+static float nd_prediction(oc *c, float max_costs, float price, unsigned band, int y_state, range *rg)
+{
+    range lrange = *rg;
+    float costs;
+    {   /* the range's DC part, weight in the DC format of the normal model (:381-398) */
+        const float x = ip_image_state(c, rg->image, rg->address, rg->level, 0);
+        const float y = ip_state_state(c, 0, 0, rg->level);
+        const float wgt = quant(x / y, c->cm[0].dc_rpf);
+        const int16_t s[2] = { 0, -1 };
+        lrange.into[0] = 0; lrange.into[1] = FA_NO_EDGE;
+        lrange.weight[0] = wgt;
+        lrange.mv_coord_bits = 0; lrange.mv_tree_bits = 0;
+        lrange.nd_tree_bits = tree_bits(c, 0, lrange.level, 1);
+        lrange.nd_weights_bits = 0;
+        lrange.tree_bits = 0; lrange.matrix_bits = 0;
+        lrange.weights_bits = coeff_bits(c, &c->cm[0], &wgt, s, rg->level);
+    }
+    costs = price * (lrange.weights_bits + lrange.nd_tree_bits);
+    if (costs < max_costs) {
+        float *block_pixels = c->pixels, *tables, *pixels;
+        const unsigned last_state = c->w->states - 1, size = fa_size_of_level(rg->level);
+        range rrange;
+        unsigned n;
+        {   /* original - approximation (:417-427) */
+            const float wgt = -lrange.weight[0] * img_of(c, 0)[0];
+            const float *src = c->pixels + (size_t) rg->address * size;
+            pixels = (float *) calloc(fa_size_of_level(c->lc_max), sizeof(float));
+            for (n = 0; n < size; n++) pixels[n] = src[n] + wgt;
+            c->pixels = pixels;
+        }
+        rrange = *rg;
+        rrange.tree_bits = rrange.matrix_bits = rrange.weights_bits = 0;
+        rrange.mv_coord_bits = rrange.mv_tree_bits = 0;
+        rrange.nd_tree_bits = rrange.nd_weights_bits = 0;
+        rrange.image = 0; rrange.address = 0;
+        tables = residual_tables_begin(c, last_state);
+        compute_ip_images_state(c, rrange.image, rrange.address, rrange.level, 1, 0);
+        costs += subdivide(c, max_costs - costs, band, y_state, &rrange, 0, 1);
+        if (costs < max_costs && rrange.tree != FA_RANGE) {
+            const unsigned img = rg->image, adr = rg->address;
+            unsigned e;
+            *rg = rrange;
+            rg->image = img; rg->address = adr;
+            rg->nd_tree_bits += lrange.nd_tree_bits;
+            rg->nd_weights_bits += lrange.weights_bits;
+            for (e = 0; lrange.into[e] != FA_NO_EDGE; e++) {
+                rg->into[e] = lrange.into[e];
+                rg->weight[e] = lrange.weight[e];
+            }
+            rg->into[e] = FA_NO_EDGE;
+            rg->prediction = (int) e;
+            residual_tables_end(c, tables, last_state, 1);
+        } else {
+            residual_tables_end(c, tables, last_state, 0);
+            costs = FA_MAXCOSTS;
+        }
+        free(pixels);
+        c->pixels = block_pixels;
+    } else
+        costs = FA_MAXCOSTS;
+    return costs;
+}
+
+/* the models a subdivide() call may have to go back to */
+typedef struct snapshot {
+    rle_model pm[2];
+    int16_t  *cbuf;
+    unsigned *tm;
+    unsigned  states;
+} snapshot;
+
+static void snap_take(oc *c, snapshot *sn)
+{
+    sn->pm[0] = c->pl[0].m; sn->pm[1] = c->pl[1].m;
+    sn->cbuf = (int16_t *) malloc(c->cbuf_n * sizeof(int16_t));
+    memcpy(sn->cbuf, c->cbuf, c->cbuf_n * sizeof(int16_t));
+    sn->tm = NULL;
+}
+
+static void snap_take_tm(oc *c, snapshot *sn)
+{
+    sn->tm = (unsigned *) malloc((size_t) 4 * c->ML * sizeof(unsigned));
+    memcpy(sn->tm, c->tm, (size_t) 4 * c->ML * sizeof(unsigned));
+}
+
+static void snap_models(oc *c, const snapshot *sn)        /* pools + coefficient models */
+{
+    c->pl[0].m = sn->pm[0]; c->pl[1].m = sn->pm[1];
+    memcpy(c->cbuf, sn->cbuf, c->cbuf_n * sizeof(int16_t));
+}
+
+static void snap_tm(oc *c, const snapshot *sn)
+{
+    memcpy(c->tm, sn->tm, (size_t) 4 * c->ML * sizeof(unsigned));
+}
+
+static void snap_free(snapshot *sn) { free(sn->cbuf); free(sn->tm); }
+
+/* predict_range, codec/prediction.c:96-208.  `entry`: models at the entry of the enclosing
+ * subdivide() call, `states`: wfa->states at that time. */
+static float predict_range(oc *c, float max_costs, float price, range *rg, unsigned band, int y_state,
+                           unsigned states, const snapshot *entry)
+{
+    fa_wfa *w = c->w;
+    snapshot rec;
+    const unsigned rec_states = w->states;
+    state_data *rec_data;
+    int16_t *tail[2] = { NULL, NULL };
+    unsigned k;
+    float costs;
+
+    snap_take(c, &rec);
+    snap_take_tm(c, &rec);
+    rec_data = store_state_data(c, states, rec_states - 1);
+    /* the pool snapshots share one states[] array per pool (see rle_model): what the recursion
+     * appended behind the entry length is kept aside, the prediction appends there too */
+    for (k = 0; k < 2; k++)
+        if (!c->pl[k].constant && rec.pm[k].n > entry->pm[k].n) {
+            tail[k] = (int16_t *) malloc((rec.pm[k].n - entry->pm[k].n) * sizeof(int16_t));
+            memcpy(tail[k], c->pl[k].states + entry->pm[k].n, (rec.pm[k].n - entry->pm[k].n) * sizeof(int16_t));
+        }
+    w->states = states;
+    snap_tm(c, entry);
+    snap_models(c, entry);
+
+    if (c->mt.frame_type == FA_I_FRAME) costs = nd_prediction(c, max_costs, price, band, y_state, rg);
+    else costs = mc_prediction(c, max_costs, price, band, y_state, rg);
+
+    if (costs < FA_MAXCOSTS) {
+        if (rec_data) free_state_data(rec_data, rec_states - states);
+        costs = range_costs(rg, price);
+    } else {
+        snap_models(c, &rec);
+        snap_tm(c, &rec);
+        for (k = 0; k < 2; k++)
+            if (tail[k])
+                memcpy(c->pl[k].states + entry->pm[k].n, tail[k], (rec.pm[k].n - entry->pm[k].n) * sizeof(int16_t));
+        rg->prediction = 0;
+        if (w->states != states) remove_states(c, states);
+        restore_state_data(c, states, rec_states - 1, rec_data);
+        costs = FA_MAXCOSTS;
+    }
+    free(tail[0]); free(tail[1]);
+    snap_free(&rec);
+    return costs;
+}
+
+/* ------------------------------------------------------------------ subdivide (codec/subdivide.c:60-502) */
+
+static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range *rg, int prediction, int delta)
 {
     fa_wfa *w = c->w;
     float subdivide_costs, lincomb_costs, price;
-    int new_y_state[2];
-    unsigned states, label;
-    rle_model pool0, pool_lc;
-    int16_t *coeff0, *coeff_lc, *ct0, *ct_lc;
-    unsigned *tm0;
+    int new_y_state[2], try_mc, try_nd;
+    unsigned label;
+    snapshot entry, lc;
     range lrange, rrange, child[2];
-    size_t csz = c->coeff_size * sizeof(int16_t), tsz = c->coeff_nt * sizeof(int16_t);
-    size_t tmsz = (size_t) 4 * c->ML * sizeof(unsigned);
 
     if (c->failed) return FA_MAXCOSTS;
     rg->into[0] = FA_NO_EDGE;
     rg->tree = FA_RANGE;
     if (rg->level < 3) return FA_MAXCOSTS;
     if (rg->x >= c->im->width || rg->y >= c->im->height) return 0;   /* not visible */
+
+    try_mc = prediction && c->mt.frame_type != FA_I_FRAME && rg->level >= c->p_min && rg->level <= c->p_max
+             && rg->x + fa_width_of_level(rg->level) <= c->im->width
+             && rg->y + fa_height_of_level(rg->level) <= c->im->height;
+    try_nd = prediction && c->mt.frame_type == FA_I_FRAME && rg->level >= c->p_min && rg->level <= c->p_max;
+    if (try_mc) clear_norms_table(c, rg->level);
 
     if (rg->level == c->lc_max) init_range(c, rg, band);
 
@@ -900,13 +1474,10 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
         new_y_state[0] = new_y_state[1] = FA_RANGE;
 
     /* snapshot every model the recursion may touch */
-    pool0 = c->pool;
-    coeff0 = (int16_t *) malloc(csz); ct0 = (int16_t *) malloc(tsz);
-    coeff_lc = (int16_t *) malloc(csz); ct_lc = (int16_t *) malloc(tsz);
-    tm0 = (unsigned *) malloc(tmsz);
-    memcpy(coeff0, c->coeff, csz); memcpy(ct0, c->coeff_totals, tsz);
-    memcpy(tm0, c->tm, tmsz);
-    states = w->states;
+    snap_take(c, &entry);
+    snap_take_tm(c, &entry);
+    entry.states = w->states;
+    memset(&lrange, 0, sizeof lrange);
 
     if (rg->level <= c->lc_max) {
         lrange = *rg;
@@ -914,15 +1485,19 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
         lrange.tree_bits = tree_bits(c, 0, lrange.level, 0);
         lrange.matrix_bits = 0;
         lrange.weights_bits = 0;
-        lincomb_costs = approximate_range(c, max_costs, price, c->max_elements, y_state, &lrange);
+        lrange.mv_tree_bits = try_mc ? 1 : 0;       /* mc allowed but not used */
+        lrange.mv_coord_bits = 0;
+        lrange.nd_tree_bits = 0;
+        lrange.nd_weights_bits = 0;
+        lrange.prediction = 0;
+        lincomb_costs = approximate_range(c, max_costs, price, c->max_elements, y_state, &lrange,
+                                          &c->pl[delta ? 1 : 0], &c->cm[delta ? 1 : 0]);
     } else
         lincomb_costs = FA_MAXCOSTS;
 
     /* keep the models as modified by the linear combination, continue from the snapshot */
-    pool_lc = c->pool;
-    memcpy(coeff_lc, c->coeff, csz); memcpy(ct_lc, c->coeff_totals, tsz);
-    c->pool = pool0;
-    memcpy(c->coeff, coeff0, csz); memcpy(c->coeff_totals, ct0, tsz);
+    snap_take(c, &lc);
+    snap_models(c, &entry);
 
     if (rg->level > c->lc_min) {
         memset(child, 0, sizeof child);
@@ -931,7 +1506,13 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
         rrange.matrix_bits = 0;
         rrange.weights_bits = 0;
         rrange.err = 0;
-        subdivide_costs = (rrange.tree_bits + rrange.weights_bits + rrange.matrix_bits) * price;
+        rrange.mv_tree_bits = try_mc ? 1 : 0;
+        rrange.mv_coord_bits = 0;
+        rrange.nd_tree_bits = try_nd ? tree_bits(c, 1, lrange.level, 1) : 0;
+        rrange.nd_weights_bits = 0;
+        rrange.prediction = 0;
+        subdivide_costs = (rrange.tree_bits + rrange.weights_bits + rrange.matrix_bits + rrange.mv_tree_bits
+                           + rrange.mv_coord_bits + rrange.nd_tree_bits + rrange.nd_weights_bits) * price;
 
         for (label = 0; label < 2; label++) {
             float remaining;
@@ -945,36 +1526,52 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
                              ? rrange.y + label * fa_height_of_level(rrange.level - 1) : rrange.y;
             if (label && rrange.level <= c->lc_max)
                 compute_ip_images_state(c, child[label].image, child[label].address,
-                                        child[label].level, 1, states);
+                                        child[label].level, 1, entry.states);
             remaining = fminf2(lincomb_costs, max_costs) - subdivide_costs;
             if (remaining > 0)
-                subdivide_costs += subdivide(c, remaining, band, new_y_state[label], &child[label]);
+                subdivide_costs += subdivide(c, remaining, band, new_y_state[label], &child[label],
+                                             prediction, delta);
+            else if (try_mc && child[label].level >= c->p_min)
+                fill_norms_table(c, child[label].x, child[label].y, child[label].level);
+            if (try_mc) update_norms_table(c, rrange.level);
             if (subdivide_costs >= fminf2(lincomb_costs, max_costs)) {
                 subdivide_costs = FA_MAXCOSTS;
                 break;
             }
-            rrange.err          += child[label].err;
-            rrange.tree_bits    += child[label].tree_bits;
-            rrange.matrix_bits  += child[label].matrix_bits;
-            rrange.weights_bits += child[label].weights_bits;
+            rrange.err             += child[label].err;
+            rrange.tree_bits       += child[label].tree_bits;
+            rrange.matrix_bits     += child[label].matrix_bits;
+            rrange.weights_bits    += child[label].weights_bits;
+            rrange.mv_tree_bits    += child[label].mv_tree_bits;
+            rrange.mv_coord_bits   += child[label].mv_coord_bits;
+            rrange.nd_weights_bits += child[label].nd_weights_bits;
+            rrange.nd_tree_bits    += child[label].nd_tree_bits;
             tree_update(c, child[label].tree != FA_RANGE, child[label].level, 0);
-            tree_update(c, 1, child[label].level, 1);   /* child.prediction is NO -> CHILD */
+            tree_update(c, !child[label].prediction, child[label].level, 1);
         }
     } else
         subdivide_costs = FA_MAXCOSTS;
 
+    /* third alternative: predict the range, approximate the residual (:378-407) */
+    if ((try_mc || try_nd) && !c->failed) {
+        float pc = predict_range(c, fminf2(fminf2(lincomb_costs, subdivide_costs), max_costs), price, rg,
+                                 band, y_state, entry.states, &entry);
+        if (pc < FA_MAXCOSTS) {
+            snap_free(&entry); snap_free(&lc);
+            return pc;
+        }
+    }
+
     if (lincomb_costs >= FA_MAXCOSTS && subdivide_costs >= FA_MAXCOSTS) {
-        c->pool = pool0;
-        memcpy(c->coeff, coeff0, csz); memcpy(c->coeff_totals, ct0, tsz);
-        memcpy(c->tm, tm0, tmsz);
-        if (w->states != states) remove_states(c, states);
+        snap_models(c, &entry);
+        snap_tm(c, &entry);
+        if (w->states != entry.states) remove_states(c, entry.states);
         subdivide_costs = FA_MAXCOSTS;
     } else if (lincomb_costs < subdivide_costs) {
-        c->pool = pool_lc;
-        memcpy(c->coeff, coeff_lc, csz); memcpy(c->coeff_totals, ct_lc, tsz);
-        memcpy(c->tm, tm0, tmsz);
+        snap_models(c, &lc);
+        snap_tm(c, &entry);
         *rg = lrange;
-        if (w->states != states) remove_states(c, states);
+        if (w->states != entry.states) remove_states(c, entry.states);
         subdivide_costs = lincomb_costs;
     } else {
         int aux = band > FA_Y
@@ -987,11 +1584,11 @@ static float subdivide(oc *c, float max_costs, unsigned band, int y_state, range
             fail(c, "Maximum number of states reached!");
             subdivide_costs = FA_MAXCOSTS;
         } else {
-            init_new_state(c, aux, &rrange, child, new_y_state);
+            init_new_state(c, aux, delta, &rrange, child, new_y_state);
             *rg = rrange;
         }
     }
-    free(coeff0); free(ct0); free(coeff_lc); free(ct_lc); free(tm0);
+    snap_free(&entry); snap_free(&lc);
     return subdivide_costs;
 }
 
@@ -1014,7 +1611,8 @@ static int encode_one(fa_job *job)
     oc c;
     fa_wfa *w = job->wfa;
     const fa_cparams *cp = &job->cp;
-    unsigned cap = cp->limit_states, s;
+    unsigned cap = cp->limit_states, s, l;
+    const int inter = job->frame_type != FA_I_FRAME;
     range rg;
     float costs;
 
@@ -1024,16 +1622,19 @@ static int encode_one(fa_job *job)
     c.images_level = cp->images_level; c.products_level = cp->products_level;
     c.max_elements = cp->max_elements;
     c.price = cp->price;
+    c.p_min = cp->p_min_level; c.p_max = cp->p_max_level;
     c.nimg = fa_size_of_tree(c.images_level);
     c.nprod = fa_size_of_tree(c.products_level);
     c.nlev = c.lc_max - c.images_level;
     c.ML = cp->limit_level;
     c.images = (float *) calloc((size_t) cap * c.nimg, sizeof(float));
     c.ipis = (float *) calloc((size_t) cap * c.nprod, sizeof(float));
+    c.ipis_alt = (cp->prediction || inter) ? (float *) calloc((size_t) cap * c.nprod, sizeof(float)) : NULL;
     c.gram = (float **) calloc(cap, sizeof(float *));
     c.pixels = (float *) calloc(fa_size_of_level(c.lc_max), sizeof(float));
     c.tm = (unsigned *) calloc((size_t) 4 * c.ML + 4, sizeof(unsigned));
-    c.pool_states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
+    c.pl[0].states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
+    c.pl[1].states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
     c.rem_num = (float *) calloc(cap + 2, sizeof(float));
     c.rem_den = (float *) calloc(cap + 2, sizeof(float));
     c.ipdo = (float *) calloc((size_t) (cap + 2) * MAXED, sizeof(float));
@@ -1041,21 +1642,36 @@ static int encode_one(fa_job *job)
     c.dlist = (int16_t *) calloc(cap + 4, sizeof(int16_t));
     init_matrix_tables(&c);
     if (getenv("FIASCO_ORACLE_TRACE")) c.trace = fopen(getenv("FIASCO_ORACLE_TRACE"), "wb");
+    for (s = 0; s < 3; s++) c.planes[s] = job->image->pixels[s];
+    /* motion_t (alloc_motion, codec/mwfa.c:85-126) */
+    c.mt.frame_type = job->frame_type;
+    c.mt.past = job->past; c.mt.future = job->future;
+    c.mt.range_size = (2 * cp->search_range) * (2 * cp->search_range);
+    for (s = 0; s < 2 * cp->search_range && s < 33; s++) c.mt.xbits[s] = mv_code_bits[s];
+    if (inter)
+        for (l = c.p_min; l <= c.p_max; l++) {
+            c.mt.fwd[l] = (float *) calloc(c.mt.range_size, sizeof(float));
+            c.mt.bwd[l] = (float *) calloc(c.mt.range_size, sizeof(float));
+        }
 
     append_basis_states(&c);
     tree_init(c.tm, c.tm + c.ML, c.ML);
     tree_init(c.tm + 2 * c.ML, c.tm + 3 * c.ML, c.ML);
-    pool_init(&c);
+    /* codec/coder.c:716-736: the delta pool is a second `rle' pool when residuals can occur,
+     * else the constant pool */
+    pool_init(&c, &c.pl[0], 0);
+    pool_init(&c, &c.pl[1], !(cp->prediction || inter));
     coeff_init(&c);
 
     if (!job->image->color) {
         root_range(&rg, cp->level);
-        costs = subdivide(&c, FA_MAXCOSTS, FA_GRAY, FA_RANGE, &rg);
+        costs = subdivide(&c, FA_MAXCOSTS, FA_GRAY, FA_RANGE, &rg, cp->prediction || inter, 0);
         put_stats(&job->stats[0], costs, &rg);
         if (!c.failed && rg.tree == FA_RANGE) fail(&c, "No root state generated!");
         else w->root_state = (unsigned) rg.tree;
     } else {
         int tree[3] = { FA_RANGE, FA_RANGE, FA_RANGE }, ycb = -1;
+        int16_t *own[3] = { NULL, NULL, NULL };
         unsigned band;
         for (band = FA_Y; band <= FA_CR && !c.failed; band++) {
             if (band == FA_CB) {
@@ -1067,9 +1683,18 @@ static int encode_one(fa_job *job)
                         min_level = (unsigned) (w->level_of_state[s] - 1);
                 }
                 c.lc_min = min_level;
+                if (inter) {                  /* subtract mc of luminance (:798-799) */
+                    size_t n = (size_t) job->image->width * job->image->height;
+                    for (s = 1; s < 3; s++) {
+                        own[s] = (int16_t *) malloc(n * sizeof(int16_t));
+                        memcpy(own[s], job->image->pixels[s], n * sizeof(int16_t));
+                        c.planes[s] = own[s];
+                    }
+                    subtract_mc(&c);
+                }
             }
             root_range(&rg, cp->level);
-            costs = subdivide(&c, FA_MAXCOSTS, band, tree[FA_Y], &rg);
+            costs = subdivide(&c, FA_MAXCOSTS, band, tree[FA_Y], &rg, inter && band == FA_Y, 0);
             put_stats(&job->stats[band], costs, &rg);
             if (c.failed) break;
             if (rg.tree == FA_RANGE) { fail(&c, "No root state generated for color component!"); break; }
@@ -1090,6 +1715,7 @@ static int encode_one(fa_job *job)
             append_state(&c, 1, final_distribution(w, w->states), cp->level + 2);
             w->root_state = w->states - 1;
         }
+        free(own[1]); free(own[2]);
     }
     job->lc_min_level_out = c.lc_min;
     job->status = !c.failed;
@@ -1097,9 +1723,11 @@ static int encode_one(fa_job *job)
 
     if (c.trace) fclose(c.trace);
     for (s = 0; s < cap; s++) free(c.gram[s]);
-    free(c.images); free(c.ipis); free(c.gram); free(c.pixels); free(c.tm); free(c.pool_states);
+    for (l = 0; l < FA_CAP_LEVEL + 2; l++) { free(c.mt.fwd[l]); free(c.mt.bwd[l]); }
+    free(c.images); free(c.ipis); free(c.ipis_alt); free(c.gram); free(c.pixels); free(c.tm);
+    free(c.pl[0].states); free(c.pl[1].states);
     free(c.rem_num); free(c.rem_den); free(c.ipdo); free(c.used); free(c.dlist);
-    free(c.coeff); free(c.coeff_totals);
+    free(c.cbuf);
     return job->status;
 }
 

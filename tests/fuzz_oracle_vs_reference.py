@@ -3,7 +3,9 @@ reference coder (oracle/_ref/cfiasco_ref, built from /root/reference by oracle/r
 
 Random gray/colour images x random option sets the reference CLI can express (quality, -z 0..2,
 dictionary size, RPF mantissas and ranges, chroma options, tiling options, 1..3-frame all-intra
-streams) are encoded by both command-line coders; the streams must be identical, or both must
+streams; with FUZZ_VIDEO=1 also intra prediction, prediction levels and 2..5-frame streams with
+P and B frames whose frames are displaced, noisy copies of the first) are encoded by both
+command-line coders; the streams must be identical, or both must
 fail.  Inputs on which the reference itself crashes are counted and skipped.  This widens the pin
 of the oracle beyond the committed golden vectors; the device is tied to the oracle by
 tests/fuzz_parity.py.
@@ -33,12 +35,23 @@ def one(seed):
     rng = np.random.default_rng(seed)
     colour = bool(rng.integers(0, 4) == 0)
     nfr = int(rng.choice([1, 1, 1, 2, 3]))
+    video = os.environ.get("FUZZ_VIDEO") == "1"
+    pattern = "i"
+    extra = []
+    if video:
+        pattern = str(rng.choice(["i", "ip", "ipp", "ippp", "ibp", "ibbp", "ipb", "ib", "ipbbp", "ibpbp"]))
+        nfr = 1 if pattern == "i" else int(rng.integers(2, 6))
+        if rng.integers(0, 2):
+            extra.append("--prediction")
+        if rng.integers(0, 3) == 0:
+            lo = int(rng.integers(4, 11))
+            extra += ["--min-level", str(lo), "--max-level", str(int(rng.integers(lo, 13)))]
     args = ["-q", str(rng.choice([1, 2, 5, 8, 20, 45, 60, 90, 99])), "-z", str(int(rng.integers(0, 3))),
             "--dictionary-size", str(rng.choice([1, 8, 40, 300, 10000])),
             "--rpf-mantissa", str(int(rng.integers(2, 9))), "--dc-rpf-mantissa", str(int(rng.integers(2, 9))),
             "--rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])), "--dc-rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])),
             "--chroma-qfactor", str(rng.choice([1.0, 2.0, 3.5])), "--chroma-dictionary", str(rng.choice([1, 5, 40, 63, 100])),
-            "--tiling-exponent", str(int(rng.integers(0, 6))), "--pattern", "i"]
+            "--tiling-exponent", str(int(rng.integers(0, 6))), "--pattern", pattern] + extra
     with tempfile.TemporaryDirectory() as td:
         names = []
         first = random_image(rng, colour)
@@ -48,6 +61,13 @@ def one(seed):
             p = os.path.join(td, "f%d.%s" % (f, "ppm" if colour else "pgm"))
             if f == 0:
                 open(p, "wb").write(first)
+            elif video and rng.integers(0, 5):
+                # a displaced, slightly noisy copy of the first frame: motion compensation can win
+                hl = len(first) - w * h * (3 if colour else 1)
+                a0 = np.frombuffer(first[hl:], np.uint8).reshape((h, w, 3) if colour else (h, w))
+                a = np.roll(a0, (int(rng.integers(-5, 6)) * f, int(rng.integers(-5, 6)) * f), (0, 1)).astype(np.int32)
+                a = np.clip(a + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
+                (synth.write_ppm if colour else synth.write_pgm)(p, a)
             else:
                 a = rng.integers(0, 256, (h, w, 3) if colour else (h, w)).astype(np.uint8)
                 (synth.write_ppm if colour else synth.write_pgm)(p, a)

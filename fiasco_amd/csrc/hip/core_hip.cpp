@@ -258,6 +258,11 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
+    if (cp->prediction || job->frame_type != FA_I_FRAME) {
+        snprintf(why, n, "the device coder does not run intra prediction or P/B frames yet "
+                         "(codec/prediction.c, codec/mwfa.c); there is no CPU fallback");
+        return 0;
+    }
     if (job->image->color && cp->chroma_max_states > 63) {
         snprintf(why, n, "device coder supports chroma dictionaries of at most 63 states");
         return 0;

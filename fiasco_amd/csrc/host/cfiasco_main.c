@@ -35,6 +35,9 @@ int main(int argc, char **argv)
         {"dc-rpf-mantissa", 1, 0, 10}, {"min-level", 1, 0, 11}, {"max-level", 1, 0, 12},
         {"prediction", 0, 0, 13}, {"basis-name", 1, 0, 14}, {"tiling-exponent", 1, 0, 15},
         {"limit-states", 1, 0, 16}, {"limit-level", 1, 0, 17}, {"tiling-method", 1, 0, 18},
+        /* parsed and dropped like bin/cwfa.c does (it never calls set_video_param) */
+        {"half-pixel", 0, 0, 18}, {"cross-B-search", 0, 0, 18}, {"B-as-past-ref", 0, 0, 18},
+        {"fps", 1, 0, 18},
         {0, 0, 0, 0}
     };
     int ch;

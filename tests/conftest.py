@@ -77,11 +77,11 @@ class Inputs:
         else:
             a = ent["args"]
             if ent["kind"] == "synth":
-                d = synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"]))
+                d = synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"], a.get("shift", 0)))
             elif ent["kind"] == "noise":
                 d = synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"]))
             elif ent["kind"] == "color_k":
-                d = synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"]))
+                d = synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"], 1234, a.get("shift", 0)))
             else:
                 d = synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"]))
         assert hashlib.md5(d).hexdigest() == ent["md5"], "input %s differs from the pinned md5" % name
@@ -110,9 +110,17 @@ def options_from_args(lib, args):
     title = comment = None
     rpf = dict(m=3, r=1.5, dm=5, dr=1.0)
     i = 0
+    pred, pmin, pmax = 0, 6, 10
     while i < len(args):
-        a, v = args[i], args[i + 1]
+        a = args[i]
+        if a in ("--prediction", "--half-pixel"):      # flags; cfiasco drops --half-pixel
+            pred = pred or a == "--prediction"
+            i += 1
+            continue
+        v = args[i + 1]
         if a == "-q": quality = float(v)
+        elif a == "--min-level": pmin = int(v)
+        elif a == "--max-level": pmax = int(v)
         elif a == "-z": optimize = int(v)
         elif a == "--dictionary-size": dict_size = int(v)
         elif a == "--pattern": kw["pattern"] = v
@@ -129,6 +137,7 @@ def options_from_args(lib, args):
         else: raise ValueError(a)
         i += 2
     o = lib.cli_options(optimize=optimize, dictionary_size=dict_size, **kw)
+    o.set_prediction(1 if pred else 0, pmin, pmax)
 
     def rng(r):
         return 0 if r < 1 else 1 if r < 1.5 else 2 if r < 2.0 else 3

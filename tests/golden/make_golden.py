@@ -50,6 +50,17 @@ INPUTS = {
     "carry48_c": ("file", dict(ext="ppm"), True),
     "carry74_a": ("file", dict(ext="ppm"), True), "carry74_b": ("file", dict(ext="ppm"), True),
     "carry74_c": ("file", dict(ext="ppm"), True),
+    # video: four frames of a scene that moves 3 px per frame (SURVEY App. C generator with shift)
+    "m0_128x96": ("synth", dict(w=128, h=96, seed=31, shift=0), True),
+    "m1_128x96": ("synth", dict(w=128, h=96, seed=31, shift=3), True),
+    "m2_128x96": ("synth", dict(w=128, h=96, seed=31, shift=6), True),
+    "m3_128x96": ("synth", dict(w=128, h=96, seed=31, shift=9), True),
+    "c256c":    ("color_c", dict(w=256, h=192, f=2), False),
+    # v00/v01/v02.ppm, 1280x720 smooth-chroma colour, x shifted by 3 f
+    "v00":      ("color_k", dict(w=1280, h=720, shift=0), False),
+    "v01":      ("color_k", dict(w=1280, h=720, shift=3), False),
+    "v02":      ("color_k", dict(w=1280, h=720, shift=6), False),
+    "k1080":    ("color_k", dict(w=1920, h=1080), False),
 }
 
 CASES = [
@@ -132,25 +143,39 @@ ORACLE_CASES = [
     ("o_c256_q45_chroma", ["c256"], ["-q", "45", "--chroma-qfactor", "1.0", "--chroma-dictionary", "63"]),
 ]
 
-# Streams of the reference for the scope rows that come NEXT (intra prediction,
-# P frames).  Neither the oracle nor the device covers them yet -- both refuse these option sets
-# with a message -- so no parity test reads them; they are committed now so that the round that
-# restates codec/prediction.c and codec/mwfa.c can pin against the real reference from its first
-# step.
-NEXT_CASES = [
-    ("next_pred_g256", ["g256"], ["--prediction"]),
-    ("next_pred_n128x96", ["n128x96"], ["--prediction"]),
-    ("next_pred_g96x64_q60", ["g96x64"], ["--prediction", "-q", "60"]),
-    ("next_seq2_gray_ip", ["f0_96x64", "f1_96x64"], ["--pattern", "ip"]),
-    ("next_seq2_gray_ip_pred", ["f0_96x64", "f1_96x64"], ["--pattern", "ip", "--prediction"]),
-    ("next_seq2_gray_ip_halfpel", ["f0_96x64", "f1_96x64"], ["--pattern", "ip", "--prediction", "--half-pixel"]),
+# intra prediction (codec/prediction.c), P and B frames (codec/mwfa.c,
+# codec/motion.c, the decoder that rebuilds the reference frames) -- streams of the real reference.
+VIDEO_CASES = [
+    ("pred_g256", ["g256"], ["--prediction"]),
+    ("pred_n128x96", ["n128x96"], ["--prediction"]),
+    ("pred_g96x64_q60", ["g96x64"], ["--prediction", "-q", "60"]),
+    ("pred_g256_z1", ["g256"], ["--prediction", "-z", "1"]),
+    ("pred_g256_lv79", ["g256"], ["--prediction", "--min-level", "7", "--max-level", "9"]),
+    ("pred_c256", ["c256"], ["--prediction"]),
+    ("seq2_gray_ip", ["f0_96x64", "f1_96x64"], ["--pattern", "ip"]),
+    ("seq2_gray_ip_pred", ["f0_96x64", "f1_96x64"], ["--pattern", "ip", "--prediction"]),
+    # cfiasco parses --half-pixel and never passes it on (bin/cwfa.c): same stream as above
+    ("seq2_gray_ip_halfpel", ["f0_96x64", "f1_96x64"], ["--pattern", "ip", "--prediction", "--half-pixel"]),
+    ("seq4_gray_ippp", ["m0_128x96", "m1_128x96", "m2_128x96", "m3_128x96"], []),
+    ("seq4_gray_ibbp", ["m0_128x96", "m1_128x96", "m2_128x96", "m3_128x96"], ["--pattern", "ibbp"]),
+    ("seq4_gray_ibbp_pred_q60", ["m0_128x96", "m1_128x96", "m2_128x96", "m3_128x96"],
+     ["--pattern", "ibbp", "--prediction", "-q", "60"]),
+    ("seq4_gray_ipbb", ["m0_128x96", "m1_128x96", "m2_128x96", "m3_128x96"], ["--pattern", "ipbb"]),
+    ("seq3_color_ipp", ["c256", "c256b", "c256c"], []),
+    ("seq3_color_ibp", ["c256", "c256b", "c256c"], ["--pattern", "ibp", "--prediction"]),
+    # SURVEY App. C known answer: 15 774 B, md5 2528889c0453c4590289ad07d9fb87e3
+    ("v720_ipp_pred", ["v00", "v01", "v02"], ["--prediction"]),
 ]
+
+# BASELINE config 3 on the stock reference: 1920x1080 colour at -z 1 (5639 B,
+# md5 c678f8ef9e9613ba40f49d93882b8491); lands in "cases"
+CASES.append(("k1080_z1", ["k1080"], ["-z", "1"]))
 
 
 def make_input(name):
     kind, a, _ = INPUTS[name]
     if kind == "synth":
-        return synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"])), "pgm"
+        return synth.pgm_bytes(synth.synth(a["w"], a["h"], a["seed"], a.get("shift", 0))), "pgm"
     if kind == "noise":
         return synth.pgm_bytes(synth.noise(a["w"], a["h"], a["seed"])), "pgm"
     if kind == "file":
@@ -167,7 +192,7 @@ def make_input(name):
         y, x = np.mgrid[0:a["h"], 0:a["w"]]
         return synth.pgm_bytes((x * 255 // (a["w"] - 1)).astype(np.uint8)), "pgm"
     if kind == "color_k":
-        return synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"])), "ppm"
+        return synth.ppm_bytes(synth.synth_color_k(a["w"], a["h"], 1234, a.get("shift", 0))), "ppm"
     if kind == "color_c":
         return synth.ppm_bytes(synth.synth_color_c(a["w"], a["h"], a["f"])), "ppm"
     raise ValueError(kind)
@@ -179,6 +204,9 @@ def main():
     os.makedirs(TMP, exist_ok=True)
     man = {"generator": "tests/golden/make_golden.py",
            "reference": "l-tamas/Fiasco (FIASCO 1.3) built by oracle/ref_build.sh: gcc -O2 -fcommon",
+           # what the reference was built with when these streams were produced (oracle/_ref/BUILD_INFO)
+           "reference_build": dict(l.strip().split(": ", 1) for l in
+                                   open(os.path.join(ROOT, "oracle", "_ref", "BUILD_INFO")) if ": " in l),
            "inputs": {}, "cases": []}
     paths = {}
     for name, (kind, a, commit) in INPUTS.items():
@@ -218,18 +246,21 @@ def main():
         man["oracle_cases"].append({"name": cname, "inputs": ins, "args": args, "bytes": len(data),
                                     "md5": hashlib.md5(data).hexdigest(), "file": None})
         print("%-28s %6d B  %s" % (cname, len(data), man["oracle_cases"][-1]["md5"]))
-    man["next_cases"] = []
-    for cname, ins, args in NEXT_CASES:
+    man["video_cases"] = []
+    for cname, ins, args in VIDEO_CASES:
         out = os.path.join(TMP, cname + ".fco")
         cmd = [REF, "--progress-meter", "0"] + args + ["-o", out] + [paths[i] for i in ins]
         r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
         if r.returncode != 0:
             sys.exit("reference failed on %s: %s" % (cname, r.stderr.decode()))
         data = open(out, "rb").read()
-        open(os.path.join(HERE, cname + ".fco"), "wb").write(data)
-        man["next_cases"].append({"name": cname, "inputs": ins, "args": args, "bytes": len(data),
-                                  "md5": hashlib.md5(data).hexdigest(), "file": cname + ".fco"})
-        print("%-28s %6d B  %s" % (cname, len(data), man["next_cases"][-1]["md5"]))
+        ent = {"name": cname, "inputs": ins, "args": args, "bytes": len(data),
+               "md5": hashlib.md5(data).hexdigest(), "file": None}
+        if all(INPUTS[i][2] for i in ins):
+            ent["file"] = cname + ".fco"
+            open(os.path.join(HERE, ent["file"]), "wb").write(data)
+        man["video_cases"].append(ent)
+        print("%-28s %6d B  %s" % (cname, len(data), ent["md5"]))
     json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1)
 
 

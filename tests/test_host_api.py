@@ -156,15 +156,31 @@ def test_input_template_expansion(oracle, inputs, tmp_path):
     o.delete()
 
 
-def test_unsupported_modes_are_errors_not_silence(oracle, inputs, tmp_path):
-    o = oracle.cli_options()            # default pattern ippppppppp -> 2nd frame is a P frame
-    rc = oracle.fiasco_coder([inputs.path("f0_96x64"), inputs.path("f1_96x64")],
-                             str(tmp_path / "v.fco"), 20.0, o)
-    assert rc == 0 and "P/B frames" in oracle.error_message()
-    o.set_prediction(1, 6, 10)
-    rc = oracle.fiasco_coder([inputs.path("f0_96x64")], str(tmp_path / "v.fco"), 20.0, o)
-    assert rc == 0 and "prediction" in oracle.error_message()
+def test_unsupported_modes_are_errors_not_silence(oracle, product, inputs, tmp_path):
+    """Half-pixel vectors: the reference's own half-pixel path reads outside the reference frame
+    (codec/motion.c:271 divides the vector after its conversion to unsigned), so there is nothing
+    to be compatible with -- refused with a message, before the output file is touched.  The
+    product without a GPU refuses everything loudly (no CPU fallback)."""
+    for lib in (oracle, product):
+        o = lib.cli_options()            # default pattern ippppppppp -> 2nd frame is a P frame
+        o.set_video_param(25, 1, 0, 1)
+        out = tmp_path / ("v_%s.fco" % lib.core_name())
+        out.write_bytes(b"keep")
+        rc = lib.fiasco_coder([inputs.path("f0_96x64"), inputs.path("f1_96x64")], str(out), 20.0, o)
+        assert rc == 0 and "Half-pixel" in lib.error_message()
+        o.delete()
+
+
+def test_coding_order_of_b_frames(oracle, inputs, tmp_path):
+    """video_coder (codec/coder.c:490-668) codes the future reference of a run of B frames
+    first: with pattern ibbp the frame numbers in the stream are 0, 3, 1, 2."""
+    names = [inputs.path("m%d_128x96" % i) for i in range(4)]
+    o = oracle.cli_options(pattern="ibbp")
+    out = str(tmp_path / "b.fco")
+    assert oracle.fiasco_coder(names, out, 20.0, o) == 1, oracle.error_message()
     o.delete()
+    golden = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq4_gray_ibbp.fco"), "rb").read()
+    assert open(out, "rb").read() == golden
 
 
 def test_submit_collect_on_oracle_seam(oracle, inputs):

@@ -33,6 +33,7 @@ extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t s
  * second-domain retry */
 static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
 {
+    if (cp->prediction) return true;         /* second model set, residual search: big build only */
     /* the default build reads 3 edge slots per label (frame_coder.hip FC_MAXE): a basis file
      * whose states have more goes to the big build */
     if (basis)
@@ -211,14 +212,18 @@ extern "C" void fiasco_amd_release_memory(void)
 struct Layout {
     size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
+    size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
+    int    max_save;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
-static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix)
+static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix,
+                          int max_save)
 {
     Layout L;
     size_t o = 0;
+    L.max_save = max_save;
 #define CARVE(field, bytes) do { L.field = o; o = align_up(o + (bytes), 256); } while (0)
     CARVE(gram, (size_t) NL * P * P * 4);
     CARVE(diag, (size_t) NL * P * 4);
@@ -248,7 +253,18 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(pos, (size_t) (PA + 8) * 2);
     CARVE(hits, (size_t) (PA + 8) * 4);
     CARVE(ycol0, (size_t) 2 * PA);                   /* initial y_column flags (colour streams) */
-    CARVE(snap, (size_t) 26 * 2 * 82 * 16);          /* aac snapshots of the big build: depth x 2 x n16 */
+    /* model snapshots of the big build: aac [depth][slots][n16] x 16 bytes, with prediction 5
+     * slots per depth and the tree-model snapshots [depth][2][28] behind them */
+    CARVE(snap, max_save ? (size_t) (FC_MAXDEPTH_BIG * 5 * 82 + FC_MAXDEPTH_BIG * 2 * 28) * 16
+                         : (size_t) 26 * 2 * 82 * 16);
+    /* prediction: second table set for residual blocks, block pixels + norms, displaced rows */
+    CARVE(ipis_alt, max_save ? (size_t) NS * P * 4 : 0);
+    CARVE(d5_alt, max_save ? (size_t) NA * P * 4 : 0);
+    CARVE(d4_alt, max_save && low ? (size_t) 2 * NA * P * 4 : 0);
+    CARVE(pix_save, max_save ? (size_t) (4096 + 128) * 4 : 0);
+    CARVE(sv_gram, (size_t) max_save * NL * P * 4);
+    CARVE(sv_img, (size_t) max_save * (NI + 48 + NL) * 4);
+    CARVE(sv_auto, (size_t) max_save * sizeof(FcSavedRow));
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -258,9 +274,13 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
-    if (cp->prediction || job->frame_type != FA_I_FRAME) {
-        snprintf(why, n, "the device coder does not run intra prediction or P/B frames yet "
-                         "(codec/prediction.c, codec/mwfa.c); there is no CPU fallback");
+    if (job->frame_type != FA_I_FRAME) {
+        snprintf(why, n, "the device coder does not run P/B frames yet (codec/mwfa.c); "
+                         "there is no CPU fallback");
+        return 0;
+    }
+    if (cp->prediction && cp->p_max_level - cp->lc_min_level + 1 > 9) {
+        snprintf(why, n, "prediction over more than 9 block levels is not supported by the device coder");
         return 0;
     }
     if (job->image->color && cp->chroma_max_states > 63) {
@@ -409,6 +429,21 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pos = (int16_t *) (base + L.pos);
     F.hits = (int *) (base + L.hits);
     F.snap_hbm = fs.big ? (void *) (base + L.snap) : nullptr;
+    /* prediction (codec/coder.c:716-745): gray frames try it from the root; a colour frame only
+     * gets the second rle pool (intra prediction is never asked for its bands, :805-806) */
+    F.pred_on = cp->prediction ? 1 : 0;
+    F.pred_root = cp->prediction && !job->image->color ? 1 : 0;
+    F.frame_type = job->frame_type;
+    F.p_min = (int) cp->p_min_level; F.p_max = (int) cp->p_max_level;
+    F.d_rpf_mant = (int) cp->d_rpf.mantissa_bits; F.d_dc_mant = (int) cp->d_dc_rpf.mantissa_bits;
+    F.d_rpf_range = cp->d_rpf.range; F.d_dc_range = cp->d_dc_rpf.range;
+    F.d_dcs = 1 << (1 + F.d_dc_mant); F.d_sy = 1 << (1 + F.d_rpf_mant);
+    F.d_coeff_size = (F.lc_max - F.lc_min + 1) * F.d_sy + F.d_dcs;
+    F.ipis_alt = (float *) (base + L.ipis_alt); F.d5_alt = (float *) (base + L.d5_alt);
+    F.d4_alt = (float *) (base + L.d4_alt); F.pix_save = (float *) (base + L.pix_save);
+    F.sv_gram = (float *) (base + L.sv_gram); F.sv_img = (float *) (base + L.sv_img);
+    F.sv_auto = (FcSavedRow *) (base + L.sv_auto);
+    F.max_save = L.max_save;
 }
 
 /* allocate the slab of one frame for capacity fs.P and upload its pixel plane */
@@ -424,7 +459,14 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     int NI = (int) fa_size_of_tree(cp->images_level);
     size_t npix = (size_t) job->image->width * job->image->height;
     const int bands = job->image->color ? 3 : 1;
-    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands);
+    /* states a prediction attempt can displace: the nodes of a subtree from the largest
+     * predicted level down to the smallest block level */
+    int max_save = 0;
+    if (cp->prediction) {
+        int span = (int) cp->p_max_level - (int) cp->lc_min_level + 1;
+        max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
+    }
+    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     if (!fs.base) {
         snprintf(job->errmsg, sizeof job->errmsg, "out of HBM: frame needs %.2f GiB", fs.L.total / 1073741824.0);

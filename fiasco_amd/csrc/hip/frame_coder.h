@@ -28,6 +28,8 @@
 #define FC_MAXED    5
 #define FC_BLOCK    256         /* threads per frame workgroup */
 #define FC_MAXDEPTH 22          /* recursion depth bound: level <= 26, lc_min >= 6 */
+#define FC_MAXDEPTH_BIG 32      /* big build: + the residual search of a predicted range */
+#define FC_MAXSAVE  512         /* states a prediction attempt can displace: 2^(12 - 4 + 1) */
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */
 #define FC_MAXCOEFF_BIG 640     /* big build: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
 #define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
@@ -76,6 +78,21 @@ typedef struct DevFrame {
     const uint8_t *ycol0;  /* what ycol starts from: the flags the previous frame of a colour stream
                             * left behind (fa_job.ycol_carry); null = zeros (fresh wfa_t) */
     void    *snap_hbm;     /* big build: home of the aac model snapshots when they outgrow LDS */
+    /* ---- prediction (codec/prediction.c; big build only) ---- */
+    int      pred_root;    /* `prediction' argument of the band-0 root subdivide() call */
+    int      pred_on;      /* options.prediction || frame is not intra: second rle pool, ND section */
+    int      frame_type;   /* 0 I, 1 P, 2 B */
+    int      p_min, p_max; /* wi->p_min_level, p_max_level */
+    int      d_rpf_mant, d_dc_mant;        /* delta coefficient model (d_rpf / d_dc_rpf) */
+    float    d_rpf_range, d_dc_range;
+    int      d_coeff_size, d_dcs, d_sy;
+    float   *ipis_alt, *d5_alt, *d4_alt;   /* tables of the residual block of a predicted range */
+    float   *pix_save;     /* [FC_PIXELS + FC_PIXELS/32] block pixels + norms while a residual is searched */
+    /* rows of the states a prediction attempt displaces (store_state_data, prediction.c:502-565) */
+    float   *sv_gram;      /* [max_save][NL][P] */
+    float   *sv_img;       /* [max_save][NI + 48 + NL]  image row, imgT / imgT4 columns, diagonal */
+    struct FcSavedRow *sv_auto;   /* [max_save] automaton rows */
+    int      max_save;
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     int     *hits;         /* [P] edge-target histogram for the chroma domain list */
@@ -103,6 +120,16 @@ typedef struct DevFrame {
     struct FcTrace *trace;
     int      trace_cap, trace_n;
 } DevFrame;
+
+/* automaton row of one state, as store_state_data keeps it */
+typedef struct FcSavedRow {
+    int16_t  tree[2], into[2][6];
+    float    weight[2][6];
+    float    final_d;
+    uint16_t x[2], y[2];
+    int16_t  pos;
+    uint8_t  level, dtype, ycol[2], tables;      /* tables: table rows were saved too */
+} FcSavedRow;
 
 /* one record per approximate_range call; identical layout in oracle/oracle_core.c */
 typedef struct FcTrace {

@@ -102,15 +102,25 @@
 #define BIGF    3.0e38f
 #define MIN_NORM 2e-3f
 
-enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA };
+enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA,
+       OP_PRED_SETUP, OP_PRED_FINISH };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
-       PH_AFTER_APPEND };
+       PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE };
+#if FC_VARIANT_BIG
+#define FC_DEPTH FC_MAXDEPTH_BIG
+#else
+#define FC_DEPTH FC_MAXDEPTH
+#endif
 
 struct Range {
     int   x, y, image, address, level, tree;
     float weight[MAXED + 1];
     short into[MAXED + 1];
     float err, tree_bits, matrix_bits, weights_bits;
+#if FC_VARIANT_BIG
+    float nd_tree_bits, nd_weights_bits;   /* codec/cwfa.h:70-73 (the mv_* pair comes with P frames) */
+    int   prediction;
+#endif
 };
 
 struct Pool {                    /* rle model, codec/domain-pool.c:621-630 */
@@ -126,6 +136,14 @@ struct SFrame {
     float max_costs, lincomb, subdiv, ret, price;
     int   label, states, phase, leaf, coop;
     int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
+#if FC_VARIANT_BIG
+    /* prediction (codec/prediction.c:96-208): `pred` / `delta` are the arguments of the same name
+     * of subdivide(); the rec_* members are what predict_range keeps of the subdivision result */
+    int   pred, delta, try_pred, pred_done, rec_states;
+    Pool  dpool0, pool_rec, dpool_rec;
+    Range prange;                /* range of the residual search */
+    float pred_max, pred_costs, nd_w, nd_wbits, nd_tbits;
+#endif
 };
 
 struct MPState {
@@ -184,11 +202,26 @@ struct RoundBox {                    /* mp_reg.inc: winner of the running step, 
 
 struct Sh {
     RoundBox rb;
-    SFrame   st[FC_MAXDEPTH];
+    SFrame   st[FC_DEPTH];
     int      sp;
     int      op, a0, a1, a2, a3;
     Pool     pool;
     CoeffBuf cb;
+#if FC_VARIANT_BIG
+    /* the second set of models (d_domain_pool, d_coeff; codec/coder.c:716-736).  The two `rle'
+     * pools hold the same state list at all times (every state is offered to both,
+     * codec/subdivide.c:571-581), only the counters differ: pool_states / pos are shared.
+     * sh.pool / sh.cb / the quantiser in sh.par are the ACTIVE set: the normal models, or the
+     * delta models while the residual of a predicted range is searched (swapped in and out by
+     * OP_PRED_SETUP / OP_PRED_FINISH); the other set rests in dpool / dcb / dq. */
+    Pool     dpool;
+    CoeffBuf dcb;
+    struct { int rpf_mant, dc_mant, sy, dcs; float rpf_range, dc_range; } dq;
+    int      nslot;                /* aac snapshot slots per depth: 2, or 5 with prediction */
+    uint4   *snap_tm_p;            /* tree-model snapshots: snap_tm, or HBM with prediction */
+    int      pred_active, pred_lo, pred_rec;   /* a residual search is running; displaced ids */
+    unsigned pred_saved[FC_MAXSAVE / 32];      /* their table rows are in the save area */
+#endif
     uint4    snap_pool[SNAP_POOL16];
     uint4   *snap;                 /* snapshots live here: snap_pool, or HBM when they outgrow it */
     int      n16;                  /* uint4 per aac snapshot */
@@ -206,7 +239,7 @@ struct Sh {
     float    blockmin[NBLOCKMIN];
     float    pixels[FC_PIXELS];
     float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
-    unsigned long long tk[8];      /* ticks per op (lane 0) */
+    unsigned long long tk[12];     /* ticks per op (lane 0) */
     struct {
         unsigned long long bytes_mp, bytes_img, bytes_gram, n_mp, n_steps, n_blocks, n_appends,
                            n_fulleval, n_blockevals, t_mpA, t_mpB;
@@ -230,6 +263,7 @@ struct Sh {
         int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease;
         /* the same for the matching pursuit: table bases and quantiser parameters */
         float *gram, *diag, *ipis; int16_t *pos;
+        float *d5, *d4;            /* big build: the active level-5 / level-4 dot tables */
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
         float rpf_range, dc_range;
     } par;
@@ -409,6 +443,18 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 
 /* ------------------------------------------------------------------ parallel ops */
 
+/* <sub-block, state> tables in use: the block's, or -- big build, while the residual of a
+ * predicted range is searched (codec/prediction.c:302-309,443-450) -- the second set */
+#if FC_VARIANT_BIG
+#define ACT_IPIS(F, sh) ((sh).par.ipis)
+#define ACT_D5(F, sh)   ((sh).par.d5)
+#define ACT_D4(F, sh)   ((sh).par.d4)
+#else
+#define ACT_IPIS(F, sh) ((F).ipis)
+#define ACT_D5(F, sh)   ((F).d5)
+#define ACT_D4(F, sh)   ((F).d4)
+#endif
+
 /* states that can own tables: chroma states are all auxiliary (codec/subdivide.c:433-436) */
 __device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.ystates : sh.states; }
 
@@ -493,8 +539,8 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
     const int P = __builtin_amdgcn_readfirstlane(F.P), states = __builtin_amdgcn_readfirstlane(table_states(sh));
     image = __builtin_amdgcn_readfirstlane(image); address = __builtin_amdgcn_readfirstlane(address);
     level = __builtin_amdgcn_readfirstlane(level); from = __builtin_amdgcn_readfirstlane(from);
-    GLOBAL_AS float *const ipis = uniform_ptr(F.ipis);
-    GLOBAL_AS const float *const d5 = uniform_ptr((const float *) F.d5);
+    GLOBAL_AS float *const ipis = uniform_ptr(ACT_IPIS(F, sh));
+    GLOBAL_AS const float *const d5 = uniform_ptr((const float *) ACT_D5(F, sh));
     AutoTabs T;
     auto_tabs(F, T);
     for (int lv = il + 1; lv <= level; lv++) {
@@ -570,9 +616,12 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
-__device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to)
+/* na / n4: number of level-images_level and level-(images_level - 1) sub-blocks of the block in
+ * sh.pixels (NA and 2 NA for a whole block; fewer for the residual of a predicted range) */
+__device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to, int na, int n4)
 {
     const int tid = threadIdx.x, P = F.P;
+    float *const D5 = ACT_D5(F, sh);
     for (int s = from + tid; s < to; s += B) {
         if (!F.domain_type[s]) continue;
         float v[32];
@@ -581,7 +630,7 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
         /* two addresses per step: packed fp32 multiply and add (v_pk_mul_f32 / v_pk_add_f32,
          * each half rounded like the scalar op; no fused multiply-add), pixels read in pairs */
         typedef float f2 __attribute__((ext_vector_type(2)));
-        for (int a = 0; a < F.NA; a += 2) {
+        for (int a = 0; a < na; a += 2) {
             f2 ip = { 0.0f, 0.0f };
 #pragma unroll
             for (int k = 0; k < 32; k++) {
@@ -589,18 +638,19 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
                 f2 vv = { v[k], v[k] };
                 ip = ip + px * vv;
             }
-            F.d5[(size_t) a * P + s] = ip.x;
-            F.d5[(size_t) (a + 1) * P + s] = ip.y;
+            D5[(size_t) a * P + s] = ip.x;
+            if (a + 1 < na) D5[(size_t) (a + 1) * P + s] = ip.y;
         }
 #if FC_VARIANT_BIG
         if (F.gl0 < F.images_level) {
+            float *const D4 = ACT_D4(F, sh);
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = F.imgT4[(size_t) k * P + s];
-            for (int a = 0; a < 2 * F.NA; a++) {
+            for (int a = 0; a < n4; a++) {
                 float ip = 0;
 #pragma unroll
                 for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v[k];
-                F.d4[(size_t) a * P + s] = ip;
+                D4[(size_t) a * P + s] = ip;
             }
         }
 #endif
@@ -658,7 +708,7 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tp0 = wall_clock64();
 #endif
-    op_d5(F, sh, 0, table_states(sh));
+    op_d5(F, sh, 0, table_states(sh), F.NA, 2 * F.NA);
     __syncthreads();
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { unsigned long long t = wall_clock64(); sh.tk_init[0] += t - tp0; tp0 = t; }
@@ -673,10 +723,17 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     }
 }
 
+#if FC_VARIANT_BIG
+__device__ void pred_save_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s);
+#endif
+
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
 __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
 {
     const int tid = threadIdx.x, il = F.images_level, P = F.P;
+#if FC_VARIANT_BIG
+    pred_save_tables(F, sh, s);         /* residual search: the id may belong to a displaced state */
+#endif
     /* term lists of the new state s (slot 0 = tree child with weight 1 if any, then the
      * edges): twelve lanes read one row slot each (one memory round trip instead of a chain of
      * dependent ones), two lanes compact them into LDS; uniform for the whole workgroup */
@@ -837,7 +894,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         for (int k = 0; k < 32; k++) vs[k] = F.imgT[(size_t) k * P + s];
 #pragma unroll
         for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * vs[k];
-        F.d5[(size_t) a * P + s] = ip;
+        ACT_D5(F, sh)[(size_t) a * P + s] = ip;
     }
 #if FC_VARIANT_BIG
     if (F.gl0 < il)
@@ -847,7 +904,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             for (int k = 0; k < 16; k++) v4[k] = F.imgT4[(size_t) k * P + s];
 #pragma unroll
             for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v4[k];
-            F.d4[(size_t) a * P + s] = ip;
+            ACT_D4(F, sh)[(size_t) a * P + s] = ip;
         }
 #endif
     if (tid == 0) {
@@ -951,10 +1008,208 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
 }
 
 #if FC_VARIANT_BIG
+/* ------------------------------------------------------------------ prediction (codec/prediction.c)
+ *
+ * predict_range (:96-208) tries a third alternative for a range after its linear combination
+ * and its subdivision: approximate the range coarsely (its DC part for an intra frame, a motion
+ * compensated block of the reference frame otherwise), run the SAME partition search on the
+ * residual (`delta' = YES: delta pool, delta coefficient model), keep what is cheapest.  The
+ * states the subdivision appended are put aside meanwhile (store_state_data, :502-565) and the
+ * residual search re-uses their ids.  Here:
+ *   OP_PRED_SETUP   block pixels + norms -> F.pix_save, residual -> sh.pixels, tables of the
+ *                   residual block into the SECOND table set (ipis_alt / d5_alt / d4_alt: the
+ *                   reference swaps the per-state table pointers, :302-309,443-450), automaton
+ *                   rows of the displaced states -> F.sv_auto, delta models become active
+ *   op_append       copies the table rows of a displaced id to F.sv_gram / F.sv_img the first
+ *                   time the residual search appends a state with that id (copy on write)
+ *   OP_PRED_FINISH  everything back; on failure the saved rows return, on success the new
+ *                   states get zeroed <sub-block, state> rows (:342-345,481-484)
+ */
+
+/* squared norms of the sub-blocks of a block of 2^level pixels in sh.pixels, heap order */
+__device__ void block_norms(Sh &sh, int level, int ns)
+{
+    const int tid = threadIdx.x;
+    for (int slot = tid; slot < ns; slot += B) {
+        int depth = 31 - __clz(slot + 1);
+        int lv = level - depth, size = 1 << lv;
+        int adr = slot + 1 - (1 << depth);
+        float nrm = 0;
+        const float *px = sh.pixels + adr * size;
+        for (int k = 0; k < size; k++) nrm += px[k] * px[k];      /* sequential, codec/approx.c:388-389 */
+        sh.norms[slot] = nrm;
+    }
+}
+
+/* exchange the active and the resting model set (all lanes; barriers by the caller) */
+__device__ void swap_model_sets(Sh &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid < sh.n16) {
+        uint4 a = ((uint4 *) &sh.cb)[tid], b = ((uint4 *) &sh.dcb)[tid];
+        ((uint4 *) &sh.cb)[tid] = b; ((uint4 *) &sh.dcb)[tid] = a;
+    } else if (tid == 128) {
+        Pool t = sh.pool; sh.pool = sh.dpool; sh.dpool = t;
+    } else if (tid == 129) {
+        int i; float f;
+        i = sh.par.rpf_mant; sh.par.rpf_mant = sh.dq.rpf_mant; sh.dq.rpf_mant = i;
+        i = sh.par.dc_mant; sh.par.dc_mant = sh.dq.dc_mant; sh.dq.dc_mant = i;
+        i = sh.par.sy; sh.par.sy = sh.dq.sy; sh.dq.sy = i;
+        i = sh.par.dcs; sh.par.dcs = sh.dq.dcs; sh.dq.dcs = i;
+        f = sh.par.rpf_range; sh.par.rpf_range = sh.dq.rpf_range; sh.dq.rpf_range = f;
+        f = sh.par.dc_range; sh.par.dc_range = sh.dq.dc_range; sh.dq.dc_range = f;
+    }
+}
+
+/* a0 = level of the range, a1 = its address in the block; the frame on top of the stack holds
+ * the DC weight (nd_w).  States [fr.states, fr.rec_states) are the ones the subdivision made. */
+__device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int address)
+{
+    const int tid = threadIdx.x, il = F.images_level;
+    SFrame &fr = sh.st[sh.sp];
+    const int size = 1 << level, npx = 1 << F.lc_max;
+    /* block pixels and norms aside */
+    for (int i = tid; i < npx; i += B) F.pix_save[i] = sh.pixels[i];
+    for (int i = tid; i < FC_PIXELS / 32; i += B) F.pix_save[FC_PIXELS + i] = sh.norms[i];
+    /* automaton rows of the displaced states aside (store_state_data) */
+    for (int s = fr.states + tid; s < fr.rec_states; s += B) {
+        FcSavedRow &r = F.sv_auto[s - fr.states];
+        for (int l = 0; l < 2; l++) {
+            r.tree[l] = TREE(F, s, l);
+            r.x[l] = F.x[l * F.PA + s]; r.y[l] = F.y[l * F.PA + s];
+            r.ycol[l] = F.color ? F.ycol[l * F.PA + s] : 0;
+            for (int e = 0; e < 6; e++) { r.into[l][e] = INTO(F, s, l, e); r.weight[l][e] = WEIGHT(F, s, l, e); }
+        }
+        r.final_d = F.final_d[s]; r.level = F.level_of_state[s]; r.dtype = F.domain_type[s];
+        r.pos = F.pos[s]; r.tables = 0;
+    }
+    /* residual: range pixels + w, w = - weight * <image of state 0 at level 0> (:417-427) */
+    {
+        const float w = -fr.nd_w * F.img[0];
+        float v[FC_PIXELS / B];
+#pragma unroll
+        for (int it = 0; it < FC_PIXELS / B; it++) {
+            const int i = tid + it * B;
+            v[it] = i < size ? sh.pixels[address * size + i] + w : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < FC_PIXELS / B; it++) {
+            const int i = tid + it * B;
+            if (i < size) sh.pixels[i] = v[it];
+        }
+    }
+    if (tid == 0) {
+        sh.par.ipis = F.ipis_alt; sh.par.d5 = F.d5_alt; sh.par.d4 = F.d4_alt;
+        sh.pred_active = 1; sh.pred_lo = fr.states; sh.pred_rec = fr.rec_states;
+        for (int i = 0; i < FC_MAXSAVE / 32; i++) sh.pred_saved[i] = 0;
+    }
+    swap_model_sets(sh);
+    __syncthreads();
+    /* tables of the residual block for every state (compute_ip_images_state(0, 0, level, 1, 0)) */
+    if (level > il) block_norms(sh, level, (1 << (level - il)) - 1);
+    op_d5(F, sh, 0, table_states(sh), level >= il ? 1 << (level - il) : 0, level >= il - 1 ? 1 << (level - il + 1) : 0);
+    __syncthreads();
+    if (level > il) op_ipis(F, sh, 0, 0, level, 0);
+}
+
+/* copy-on-write of the table rows of a displaced state id (called by all lanes from op_append) */
+__device__ void pred_save_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
+{
+    const int tid = threadIdx.x, P = F.P, idx = s - sh.pred_lo;
+    if (!sh.pred_active || s < sh.pred_lo || s >= sh.pred_rec || idx >= F.max_save) return;   /* uniform */
+    if ((sh.pred_saved[idx >> 5] >> (idx & 31)) & 1u) return;
+    if (!F.sv_auto[idx].dtype) return;                 /* the displaced state had no tables */
+    for (int q = 0; q < F.NL; q++) {
+        const float *G = GRAM(F, q) + (size_t) s * P;
+        float *dst = F.sv_gram + ((size_t) idx * F.NL + q) * P;
+        for (int t = tid; t <= s; t += B) dst[t] = G[t];
+    }
+    {
+        float *dst = F.sv_img + (size_t) idx * (F.NI + 48 + F.NL);
+        for (int i = tid; i < F.NI; i += B) dst[i] = F.img[(size_t) s * F.NI + i];
+        if (tid < 32) dst[F.NI + tid] = F.imgT[(size_t) tid * P + s];
+        else if (tid < 48 && F.gl0 < F.images_level) dst[F.NI + tid] = F.imgT4[(size_t) (tid - 32) * P + s];
+        else if (tid >= 64 && tid < 64 + F.NL) dst[F.NI + 48 + tid - 64] = F.diag[(size_t) (tid - 64) * P + s];
+    }
+    __syncthreads();
+    if (tid == 0) { sh.pred_saved[idx >> 5] |= 1u << (idx & 31); F.sv_auto[idx].tables = 1; }
+    __syncthreads();
+}
+
+/* a0 = the prediction is kept */
+__device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__restrict__ sh, int keep)
+{
+    const int tid = threadIdx.x, P = F.P;
+    SFrame &fr = sh.st[sh.sp];
+    const int npx = 1 << F.lc_max;
+    const int new_states = sh.states;           /* states of the residual search */
+    swap_model_sets(sh);
+    for (int i = tid; i < npx; i += B) sh.pixels[i] = F.pix_save[i];
+    for (int i = tid; i < FC_PIXELS / 32; i += B) sh.norms[i] = F.pix_save[FC_PIXELS + i];
+    if (tid == 0) {
+        sh.par.ipis = F.ipis; sh.par.d5 = F.d5; sh.par.d4 = F.d4;
+        sh.pred_active = 0;
+    }
+    __syncthreads();
+    if (keep) {
+        /* the delta pool saw every append; the normal pool holds the same list */
+        if (tid == 0) { sh.pool.n = sh.dpool.n; }
+        /* rows of the new states in the block's tables: zero (:342-345,481-484); their level-5
+         * dots with the block are what later table updates start from */
+        for (int s = fr.states + tid; s < new_states; s += B)
+            if (F.domain_type[s])
+                for (int slot = 0; slot < F.NS; slot++) F.ipis[(size_t) slot * P + s] = 0.0f;
+        op_d5(F, sh, fr.states, new_states, F.NA, 2 * F.NA);
+    } else {
+        /* restore_state_data (:567-625) */
+        for (int s = fr.states + tid; s < fr.rec_states; s += B) {
+            const FcSavedRow &r = F.sv_auto[s - fr.states];
+            for (int l = 0; l < 2; l++) {
+                TREE(F, s, l) = r.tree[l];
+                F.x[l * F.PA + s] = r.x[l]; F.y[l * F.PA + s] = r.y[l];
+                if (F.color) F.ycol[l * F.PA + s] = r.ycol[l];
+                for (int e = 0; e < 6; e++) { INTO(F, s, l, e) = r.into[l][e]; WEIGHT(F, s, l, e) = r.weight[l][e]; }
+            }
+            F.final_d[s] = r.final_d; F.level_of_state[s] = r.level; F.domain_type[s] = r.dtype;
+            F.pos[s] = r.pos;
+            if (r.pos >= 0) F.pool_states[r.pos] = (short) s;
+        }
+        for (int idx = 0; idx < fr.rec_states - fr.states && idx < F.max_save; idx++) {
+            if (!((sh.pred_saved[idx >> 5] >> (idx & 31)) & 1u)) continue;      /* uniform */
+            const int s = fr.states + idx;
+            for (int q = 0; q < F.NL; q++) {
+                float *G = GRAM(F, q) + (size_t) s * P;
+                const float *src = F.sv_gram + ((size_t) idx * F.NL + q) * P;
+                for (int t = tid; t <= s; t += B) G[t] = src[t];
+            }
+            const float *src = F.sv_img + (size_t) idx * (F.NI + 48 + F.NL);
+            for (int i = tid; i < F.NI; i += B) F.img[(size_t) s * F.NI + i] = src[i];
+            if (tid < 32) F.imgT[(size_t) tid * P + s] = src[F.NI + tid];
+            else if (tid < 48 && F.gl0 < F.images_level) F.imgT4[(size_t) (tid - 32) * P + s] = src[F.NI + tid];
+            else if (tid >= 64 && tid < 64 + F.NL) F.diag[(size_t) (tid - 64) * P + s] = src[F.NI + 48 + tid - 64];
+        }
+    }
+}
+#endif
+
+#if FC_VARIANT_BIG
 #define SNAP(sh) ((sh).snap)
+#define NSLOT(sh) ((sh).nslot)
+#define SNAP_TM(sh) ((sh).snap_tm_p)
+#define TM_SLOTS(sh) ((sh).nslot == 5 ? 2 : 1)
 #else
 #define SNAP(sh) ((sh).snap_pool)
+#define NSLOT(sh) 2
+#define SNAP_TM(sh) ((uint4 *) (sh).snap_tm)
+#define TM_SLOTS(sh) 1
 #endif
+/* aac snapshot slots of a depth: 0 entry, 1 after the linear combination; with prediction (big
+ * build) 2 = resting model at entry, 3 / 4 = active / resting model after the recursion
+ * (rec_coeff_model, rec_d_coeff_model of predict_range) */
+#define SNAP_AT(sh, depth, which) (SNAP(sh) + ((depth) * NSLOT(sh) + (which)) * (sh).n16)
+/* tree-model snapshots: slot 0 entry, slot 1 (prediction) after the recursion */
+#define TM_AT(sh, depth, which, ML) (SNAP_TM(sh) + ((depth) * TM_SLOTS(sh) + (which)) * (ML))
 
 /* the same snapshots taken by the whole workgroup around a linear-combination search
  * (codec/subdivide.c:188-237): before it, models -> slot 0 (+ tree model); after it, models ->
@@ -962,18 +1217,26 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
 __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, int ML)
 {
     const int tid = threadIdx.x;
-    if (tid < sh.n16) SNAP(sh)[(depth * 2 + 0) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
+    if (tid < sh.n16) SNAP_AT(sh, depth, 0)[tid] = ((const uint4 *) &sh.cb)[tid];
     else if (tid >= 96 && tid < 96 + ML)           /* n16 <= 82 (FC_MAXCOEFF_BIG), ML <= 26 */
-        ((uint4 *) (sh.snap_tm + depth * 4 * ML))[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
+        TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
     else if (tid == 128) fr.pool0 = sh.pool;
+#if FC_VARIANT_BIG
+    /* a node outside a residual search also keeps the resting (delta) models: a prediction
+     * further down may change them, and this node may have to go back (subdivide.c:189-191) */
+    else if (sh.nslot == 5 && !fr.delta) {
+        if (tid == 129) fr.dpool0 = sh.dpool;
+        else if (tid >= 160 && tid < 160 + sh.n16) SNAP_AT(sh, depth, 2)[tid - 160] = ((const uint4 *) &sh.dcb)[tid - 160];
+    }
+#endif
 }
 
 __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
 {
     const int tid = threadIdx.x;
     if (tid < sh.n16) {
-        SNAP(sh)[(depth * 2 + 1) * sh.n16 + tid] = ((const uint4 *) &sh.cb)[tid];
-        ((uint4 *) &sh.cb)[tid] = SNAP(sh)[(depth * 2 + 0) * sh.n16 + tid];
+        SNAP_AT(sh, depth, 1)[tid] = ((const uint4 *) &sh.cb)[tid];
+        ((uint4 *) &sh.cb)[tid] = SNAP_AT(sh, depth, 0)[tid];
     } else if (tid == 128) {
         fr.pool_lc = sh.pool;
         sh.pool = fr.pool0;
@@ -1016,22 +1279,35 @@ __device__ __forceinline__ void copy16(uint4 *dst, const uint4 *src, int n)
 
 __device__ void snap_save(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    copy16(SNAP(sh) + (depth * 2 + which) * sh.n16, (const uint4 *) &sh.cb, sh.n16);
+    copy16(SNAP_AT(sh, depth, which), (const uint4 *) &sh.cb, sh.n16);
 }
 
 __device__ void snap_load(const DevFrame &F, Sh &sh, int depth, int which)
 {
-    copy16((uint4 *) &sh.cb, SNAP(sh) + (depth * 2 + which) * sh.n16, sh.n16);
+    copy16((uint4 *) &sh.cb, SNAP_AT(sh, depth, which), sh.n16);
 }
 
-__device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML)
+#if FC_VARIANT_BIG
+/* the resting coefficient model (sh.dcb) */
+__device__ void snap_save_d(Sh &sh, int depth, int which)
 {
-    copy16((uint4 *) (sh.snap_tm + depth * 4 * ML), (const uint4 *) sh.tm, ML);      /* 4*ML words */
+    copy16(SNAP_AT(sh, depth, which), (const uint4 *) &sh.dcb, sh.n16);
 }
 
-__device__ __forceinline__ void tm_load(Sh &sh, int depth, int ML)
+__device__ void snap_load_d(Sh &sh, int depth, int which)
 {
-    copy16((uint4 *) sh.tm, (const uint4 *) (sh.snap_tm + depth * 4 * ML), ML);
+    copy16((uint4 *) &sh.dcb, SNAP_AT(sh, depth, which), sh.n16);
+}
+#endif
+
+__device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML, int which = 0)
+{
+    copy16(TM_AT(sh, depth, which, ML), (const uint4 *) sh.tm, ML);      /* 4*ML words */
+}
+
+__device__ __forceinline__ void tm_load(Sh &sh, int depth, int ML, int which = 0)
+{
+    copy16((uint4 *) sh.tm, TM_AT(sh, depth, which, ML), ML);
 }
 
 /* wfalib.c:152-180 */
@@ -1056,6 +1332,9 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
     if (!aux && sh.pool.n < sh.pool.max_domains) {
         F.pos[s] = (short) sh.pool.n;
         F.pool_states[sh.pool.n++] = (short) s;
+#if FC_VARIANT_BIG
+        if (sh.nslot == 5) sh.dpool.n = sh.pool.n;      /* one list, two sets of counters */
+#endif
     }
     fr.rrange.into[0] = NOEDGE;
     fr.rrange.tree = s;
@@ -1119,6 +1398,11 @@ __device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_s
     r.max_costs = MAXCOSTS;
     r.y_state = y_state;
     r.phase = PH_ENTER;
+#if FC_VARIANT_BIG
+    r.rg.nd_tree_bits = r.rg.nd_weights_bits = 0; r.rg.prediction = 0;
+    r.pred = sh.band == 0 ? F.pred_root : 0;     /* codec/coder.c:743-745,805-806 */
+    r.delta = 0;
+#endif
     sh.sp = 0;
 }
 
@@ -1189,6 +1473,11 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             if (rg.x >= sh.par.width || rg.y >= sh.par.height) { fr.ret = 0; goto pop; }
             fr.price = sh.par.price;
             if (sh.band) fr.price *= sh.par.chroma_decrease;
+#if FC_VARIANT_BIG
+            /* try_nd (codec/subdivide.c:149-151); P/B frames (try_mc) are not on the device yet */
+            fr.try_pred = fr.pred && F.frame_type == 0 && rg.level >= F.p_min && rg.level <= F.p_max;
+            fr.pred_done = 0;
+#endif
             fr.phase = PH_AFTER_INIT;
             if (rg.level == sh.par.lc_max) {
                 rg.address = rg.image = 0;
@@ -1205,6 +1494,9 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
              * touched without children -- the reference's duplicate/restore pairs
              * (codec/subdivide.c:188-237,404-468) are no-ops for it. */
             fr.leaf = rg.level <= sh.lc_min && rg.level <= sh.par.lc_max;
+#if FC_VARIANT_BIG
+            if (fr.try_pred) fr.leaf = 0;       /* predict_range goes back to the entry models */
+#endif
             /* the snapshots around a linear-combination search are taken by all lanes inside
              * OP_APPROX (snap_coop_*), not by this one */
             fr.coop = !fr.leaf && rg.level <= sh.par.lc_max;
@@ -1212,6 +1504,9 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.pool0 = sh.pool;
                 snap_save(F, sh, sh.sp, 0);
                 tm_save(sh, sh.sp, ML);
+#if FC_VARIANT_BIG
+                if (sh.nslot == 5 && !fr.delta) { fr.dpool0 = sh.dpool; snap_save_d(sh, sh.sp, 2); }
+#endif
             }
             fr.states = sh.states;
             for (int l = 0; l < 2; l++)                 /* codec/subdivide.c:167-173 */
@@ -1223,6 +1518,9 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.lrange.tree_bits = tree_bits_dev(sh, ML, 0, rg.level, 0);
                 fr.lrange.matrix_bits = 0;
                 fr.lrange.weights_bits = 0;
+#if FC_VARIANT_BIG
+                fr.lrange.nd_tree_bits = 0; fr.lrange.nd_weights_bits = 0; fr.lrange.prediction = 0;
+#endif
                 sh.op = OP_APPROX;
                 return;
             }
@@ -1247,13 +1545,25 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
                 for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
                 z.err = z.tree_bits = z.matrix_bits = z.weights_bits = 0;
+#if FC_VARIANT_BIG
+                z.nd_tree_bits = z.nd_weights_bits = 0; z.prediction = 0;
+#endif
                 fr.child[0] = z; fr.child[1] = z;
                 fr.rrange = rg;
                 fr.rrange.tree_bits = tree_bits_dev(sh, ML, 1, rg.level, 0);
                 fr.rrange.matrix_bits = 0;
                 fr.rrange.weights_bits = 0;
                 fr.rrange.err = 0;
+#if FC_VARIANT_BIG
+                /* codec/subdivide.c:259-271 (the mv terms are zero in an intra frame) */
+                fr.rrange.nd_tree_bits = fr.try_pred ? tree_bits_dev(sh, ML, 1, rg.level, 1) : 0.0f;
+                fr.rrange.nd_weights_bits = 0;
+                fr.rrange.prediction = 0;
+                fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits
+                             + 0.0f + 0.0f + fr.rrange.nd_tree_bits + fr.rrange.nd_weights_bits) * fr.price;
+#else
                 fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits) * fr.price;
+#endif
                 fr.label = 0;
                 fr.phase = PH_CHILD;
             } else {
@@ -1285,12 +1595,15 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             fr.phase = PH_CHILD_RET;
             fr.ret = 0;
             if (remaining > 0) {
-                if (sh.sp + 1 >= FC_MAXDEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
+                if (sh.sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
                 SFrame &cf = sh.st[sh.sp + 1];
                 cf.rg = fr.child[fr.label];
                 cf.y_state = fr.ny[fr.label];
                 cf.max_costs = remaining;
                 cf.phase = PH_ENTER;
+#if FC_VARIANT_BIG
+                cf.pred = fr.pred; cf.delta = fr.delta;
+#endif
                 sh.sp++;
                 break;                              /* child result arrives in fr.ret */
             }
@@ -1311,14 +1624,24 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             fr.rrange.tree_bits    += ch.tree_bits;
             fr.rrange.matrix_bits  += ch.matrix_bits;
             fr.rrange.weights_bits += ch.weights_bits;
+#if FC_VARIANT_BIG
+            fr.rrange.nd_weights_bits += ch.nd_weights_bits;
+            fr.rrange.nd_tree_bits    += ch.nd_tree_bits;
+            tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
+            tree_update_dev(sh, ML, !ch.prediction, ch.level, 1);     /* subdivide.c:371-372 */
+#else
             tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
             tree_update_dev(sh, ML, 1, ch.level, 1);
+#endif
             fr.label = label + 1;
             fr.phase = fr.label < 2 ? PH_CHILD : PH_DECIDE;
             break;
         }
         case PH_DECIDE: {
             Range &rg = fr.rg;
+#if FC_VARIANT_BIG
+            if (fr.try_pred && !fr.pred_done && !sh.failed) { fr.phase = PH_PRED_BEGIN; break; }
+#endif
             if (fr.leaf) {                       /* models are already what they have to be */
                 if (fr.lincomb < MAXCOSTS) { rg = fr.lrange; fr.ret = fr.lincomb; }
                 else fr.ret = MAXCOSTS;
@@ -1327,6 +1650,9 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sh.sp, 0);
                 tm_load(sh, sh.sp, ML);
+#if FC_VARIANT_BIG
+                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sh.sp, 2); }
+#endif
                 sh.states = fr.states;
                 if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
                 fr.ret = MAXCOSTS;
@@ -1335,6 +1661,10 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 sh.pool = fr.pool_lc;
                 snap_load(F, sh, sh.sp, 1);
                 tm_load(sh, sh.sp, ML);
+#if FC_VARIANT_BIG
+                /* the linear combination left the resting models as they were at the entry */
+                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sh.sp, 2); }
+#endif
                 rg = fr.lrange;
                 sh.states = fr.states;
                 if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
@@ -1343,6 +1673,11 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             } else {
                 int aux = sh.band > 0 || rg.x + (int) width_of_level(rg.level) > sh.par.width
                           || rg.y + (int) height_of_level(rg.level) > sh.par.height;
+#if FC_VARIANT_BIG
+                /* with a second rle pool as delta pool a state that neither pool takes keeps no
+                 * tables (codec/subdivide.c:571-583,607; the constant pool takes every state) */
+                if (F.pred_on && sh.pool.n >= sh.pool.max_domains) aux = 1;
+#endif
                 if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
                 store_new_state(F, sh, fr, aux);
                 fr.phase = PH_AFTER_APPEND;
@@ -1357,11 +1692,109 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             fr.ret = fr.subdiv;
             goto pop;
         }
+#if FC_VARIANT_BIG
+        case PH_PRED_BEGIN: {                /* predict_range + nd_prediction, prediction.c:96-150,371-404 */
+            Range &rg = fr.rg;
+            const int il = sh.par.images_level, P = sh.par.P;
+            float maxc = fr.lincomb > fr.subdiv ? fr.subdiv : fr.lincomb;
+            if (maxc > fr.max_costs) maxc = fr.max_costs;
+            fr.pred_done = 1;
+            fr.pred_max = maxc;
+            fr.rec_states = sh.states;
+            /* what the recursion left behind */
+            fr.pool_rec = sh.pool; fr.dpool_rec = sh.dpool;
+            snap_save(F, sh, sh.sp, 3); snap_save_d(sh, sh.sp, 4); tm_save(sh, sh.sp, ML, 1);
+            /* back to the models of the entry */
+            sh.pool = fr.pool0; sh.dpool = fr.dpool0;
+            snap_load(F, sh, sh.sp, 0); snap_load_d(sh, sh.sp, 2); tm_load(sh, sh.sp, ML, 0);
+            sh.states = fr.states;
+            if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
+            {   /* the range's DC part in the DC format of the normal model */
+                const float x = rg.level > il ? sh.par.ipis[(size_t) rg.image * P]
+                                              : (rg.level == il ? sh.par.d5 : sh.par.d4)[(size_t) rg.address * P];
+                const float y = sh.par.diag[(size_t) (rg.level - sh.par.gl0) * P];
+                const int sym = rtob_dev(x / y, sh.par.dc_mant, sh.par.dc_range);
+                const int cnt = sym < 0 ? 0 : (int) sh.cb.cnt[sym];      /* RPF_ZERO: see coeff_bits of the oracle */
+                fr.nd_w = btor_fast(sym, sh.par.dc_mant, sh.par.dc_range);
+                fr.nd_tbits = tree_bits_dev(sh, ML, 0, rg.level, 1);
+                fr.nd_wbits = (float) (0.0 - log2((double) (cnt / (float) sh.cb.tot[0])));
+            }
+            fr.pred_costs = fr.price * (fr.nd_wbits + fr.nd_tbits);
+            if (fr.pred_costs < maxc) {
+                if (fr.rec_states - fr.states > F.max_save || sh.sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; }
+                else {
+                    sh.op = OP_PRED_SETUP; sh.a0 = rg.level; sh.a1 = rg.address;
+                    fr.phase = PH_PRED_RECURSE;
+                    return;
+                }
+            }
+            /* no residual search: everything back as the recursion left it */
+            sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
+            snap_load(F, sh, sh.sp, 3); snap_load_d(sh, sh.sp, 4); tm_load(sh, sh.sp, ML, 1);
+            sh.states = fr.rec_states;
+            rg.prediction = 0;
+            fr.phase = PH_DECIDE;
+            break;
+        }
+        case PH_PRED_RECURSE: {              /* subdivide (max_costs - costs, ..., NO, YES), :432-456 */
+            SFrame &cf = sh.st[sh.sp + 1];
+            cf.rg = fr.rg;
+            cf.rg.tree_bits = cf.rg.matrix_bits = cf.rg.weights_bits = 0;
+            cf.rg.nd_tree_bits = cf.rg.nd_weights_bits = 0;
+            cf.rg.image = 0; cf.rg.address = 0;
+            cf.y_state = fr.y_state;
+            cf.max_costs = fr.pred_max - fr.pred_costs;
+            cf.phase = PH_ENTER;
+            cf.pred = 0; cf.delta = 1;
+            fr.phase = PH_PRED_RET;
+            sh.sp++;
+            break;
+        }
+        case PH_PRED_RET: {
+            const float costs = fr.pred_costs + fr.ret;
+            const int keep = !sh.failed && costs < fr.pred_max && fr.prange.tree != RANGE_;
+            fr.pred_costs = costs;
+            sh.op = OP_PRED_FINISH; sh.a0 = keep;
+            fr.phase = PH_PRED_DONE;
+            fr.label = keep;                 /* remembered for PH_PRED_DONE */
+            return;
+        }
+        case PH_PRED_DONE: {
+            Range &rg = fr.rg;
+            if (fr.label) {                  /* use the prediction, prediction.c:460-485,152-180 */
+                const int img = rg.image, adr = rg.address;
+                rg = fr.prange;
+                rg.image = img; rg.address = adr;
+                rg.nd_tree_bits += fr.nd_tbits;
+                rg.nd_weights_bits += fr.nd_wbits;
+                rg.into[0] = 0; rg.weight[0] = fr.nd_w; rg.into[1] = NOEDGE;
+                rg.prediction = 1;
+                if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
+                fr.ret = (rg.tree_bits + rg.matrix_bits + rg.weights_bits + 0.0f + 0.0f + rg.nd_tree_bits
+                          + rg.nd_weights_bits) * fr.price + rg.err;
+                goto pop;
+            }
+            sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
+            snap_load(F, sh, sh.sp, 3); snap_load_d(sh, sh.sp, 4); tm_load(sh, sh.sp, ML, 1);
+            sh.states = fr.rec_states;
+            {   /* columns of ids the residual search used are stale in older rows */
+                const int lim = fr.states & ~(GRAM_FB - 1);
+                if (sh.flim > lim) sh.flim = lim;
+            }
+            rg.prediction = 0;
+            fr.phase = PH_DECIDE;
+            break;
+        }
+#endif
         }
         continue;
     pop:
         if (sh.sp > 0) {
             SFrame &pf = sh.st[sh.sp - 1];
+#if FC_VARIANT_BIG
+            if (pf.phase == PH_PRED_RET) pf.prange = fr.rg;
+            else
+#endif
             pf.child[pf.label] = fr.rg;
             pf.ret = fr.ret;
         }
@@ -1480,20 +1913,53 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         /* aac model, all-ones (coeff.c:297-310) */
         sh.n16 = (32 + 2 * F.coeff_size + 15) / 16;
 #if FC_VARIANT_BIG
-        /* snapshots that outgrow LDS (wide level window x many mantissa symbols) live in HBM */
-        sh.snap = (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16 && F.snap_hbm ? (uint4 *) F.snap_hbm : sh.snap_pool;
+        if (F.pred_on && (32 + 2 * F.d_coeff_size + 15) / 16 > sh.n16) sh.n16 = (32 + 2 * F.d_coeff_size + 15) / 16;
+        sh.nslot = F.pred_on ? 5 : 2;
+        /* snapshots that outgrow LDS (wide level window x many mantissa symbols) live in HBM; with
+         * prediction (5 slots per depth, deeper stack) always: aac snapshots in the first part of
+         * the area, tree-model snapshots behind them */
+        sh.snap = (F.pred_on || (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16) && F.snap_hbm
+                  ? (uint4 *) F.snap_hbm : sh.snap_pool;
+        sh.snap_tm_p = F.pred_on && F.snap_hbm ? (uint4 *) F.snap_hbm + FC_DEPTH * 5 * 82 : (uint4 *) sh.snap_tm;
+        sh.pred_active = 0; sh.pred_lo = sh.pred_rec = 0;
 #endif
-        if (((F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16 && !(FC_VARIANT_BIG && F.snap_hbm))
-            || (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS || F.coeff_nt > 16
-            || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
-            || F.level - F.lc_min + 2 > FC_MAXDEPTH
-            || F.max_elements > FC_MAXE)             /* term slots of the table ops */
-            sh.failed = FC_ERR_INTERNAL;
+        {
+            const int depth_need = F.level - F.lc_min + 2
+#if FC_VARIANT_BIG
+                                   + (F.pred_on ? F.p_max - F.lc_min + 2 : 0)
+#endif
+                                   ;
+#if FC_VARIANT_BIG
+            const bool snap_lds = sh.snap == &sh.snap_pool[0];
+            const bool tm_lds = (const void *) sh.snap_tm_p == (const void *) &sh.snap_tm[0];
+#else
+            const bool snap_lds = true, tm_lds = true;
+#endif
+            if ((snap_lds && (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16)
+                || (tm_lds && (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS) || F.coeff_nt > 16
+                || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
+                || depth_need > FC_DEPTH
+                || F.max_elements > FC_MAXE               /* term slots of the table ops */
+                || (!FC_VARIANT_BIG && F.pred_on))        /* prediction needs the big build */
+                sh.failed = FC_ERR_INTERNAL;
+        }
         for (int i = 0; i < (FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF); i++) sh.cb.cnt[i] = 0;
         for (int i = 0; i < 16; i++) sh.cb.tot[i] = 0;
         for (int i = 0; i < F.coeff_size; i++) sh.cb.cnt[i] = 1;
         sh.cb.tot[0] = (short) F.dcs;
         for (int i = 1; i < F.coeff_nt; i++) sh.cb.tot[i] = (short) F.sy;
+#if FC_VARIANT_BIG
+        /* d_coeff (codec/coder.c:732-736) and the second rle pool over the same basis states */
+        for (int i = 0; i < FC_MAXCOEFF_BIG; i++) sh.dcb.cnt[i] = 0;
+        for (int i = 0; i < 16; i++) sh.dcb.tot[i] = 0;
+        for (int i = 0; i < F.d_coeff_size; i++) sh.dcb.cnt[i] = 1;
+        sh.dcb.tot[0] = (short) F.d_dcs;
+        for (int i = 1; i < F.coeff_nt; i++) sh.dcb.tot[i] = (short) F.d_sy;
+        sh.dpool = sh.pool;
+        sh.dq.rpf_mant = F.d_rpf_mant; sh.dq.dc_mant = F.d_dc_mant; sh.dq.sy = F.d_sy; sh.dq.dcs = F.d_dcs;
+        sh.dq.rpf_range = F.d_rpf_range; sh.dq.dc_range = F.d_dc_range;
+        if (F.pred_on && F.d_coeff_size > FC_MAXCOEFF_BIG) sh.failed = FC_ERR_INTERNAL;
+#endif
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
         sh.flim = 0;
@@ -1501,6 +1967,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         sh.par.limit_states = F.limit_states; sh.par.PA = F.PA; sh.par.P = F.P; sh.par.ML = F.ML;
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
         sh.par.gram = F.gram; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
+        sh.par.d5 = F.d5; sh.par.d4 = F.d4;
         sh.par.max_elements = F.max_elements; sh.par.rpf_mant = F.rpf_mant; sh.par.dc_mant = F.dc_mant;
         sh.par.sy = F.sy; sh.par.dcs = F.dcs; sh.par.gl0 = F.gl0; sh.par.images_level = F.images_level;
         sh.par.lc_min_opt = F.lc_min; sh.par.trace_on = F.trace != nullptr;
@@ -1513,7 +1980,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = F.ycol0 ? F.ycol0[i] : (uint8_t) 0;
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
-    if (tid == 0) for (int k = 0; k < 8; k++) tk[k] = 0;
+    if (tid == 0) for (int k = 0; k < 12; k++) tk[k] = 0;
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; for (int k = 0; k < 4; k++) sh.tk_apx[k] = 0; }
 #endif
@@ -1532,6 +1999,10 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
         case OP_CHROMA:     op_chroma_pool(F, sh); break;
+#if FC_VARIANT_BIG
+        case OP_PRED_SETUP:  op_pred_setup(F, sh, sh.a0, sh.a1); break;
+        case OP_PRED_FINISH: op_pred_finish(F, sh, sh.a0); break;
+#endif
         default: break;                      /* OP_NOP */
         }
         __syncthreads();

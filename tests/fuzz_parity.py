@@ -6,7 +6,7 @@ sizes, RPF mantissas/ranges, chroma options -- encoded by both libraries through
 fiasco_amd_encode_batch; any byte difference is reported with the seed that reproduces it.
 
 usage: fuzz_parity.py [rounds] [frames_per_round] [seed0]
-environment: FUZZ_BIG=1 sizes up to 1000 x 800; FUZZ_REPL=n every frame n times in one launch (the
+environment: FUZZ_PRED=1 also intra prediction with random level windows; FUZZ_BIG=1 sizes up to 1000 x 800; FUZZ_REPL=n every frame n times in one launch (the
 replicas must agree: a full device exposes timing-dependent faults that single frames hide)
 """
 import os
@@ -53,12 +53,17 @@ def random_options(rng, lib=None):
     mant = int(rng.integers(2, 6)); dmant = int(rng.integers(2, 6))
     rr = int(rng.integers(0, 4)); dr = int(rng.integers(0, 4))
     cq = float(rng.choice([1.0, 2.0, 3.5])); cd = int(rng.choice([1, 5, 40, 63]))
-    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd)
+    pred = (0, 6, 10)
+    if os.environ.get("FUZZ_PRED") == "1" and rng.integers(0, 4):     # intra prediction (ND)
+        plo = int(rng.integers(4, 11))
+        pred = (1, plo, int(rng.integers(plo, 13)))
+    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred)
     return spec
 
 
 def apply(o, spec):
-    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd = spec
+    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred = spec
+    o.set_prediction(*pred)
     o.set_optimizations(lo, hi, el, dic, lvl)
     o.set_quantization(mant, rr, dmant, dr)
     o.set_chroma_quality(cq, cd)

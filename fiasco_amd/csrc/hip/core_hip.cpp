@@ -213,13 +213,14 @@ struct Layout {
     size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
+    size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
     int    max_save;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
 static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix,
-                          int max_save)
+                          int max_save, int inter, int plevels, int color)
 {
     Layout L;
     size_t o = 0;
@@ -249,6 +250,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(x, (size_t) 2 * PA * 2);
     CARVE(y, (size_t) 2 * PA * 2);
     CARVE(ycol, (size_t) 2 * PA);
+    CARVE(mv, inter ? (size_t) 10 * PA * 2 : 0);     /* downloaded with the automaton */
     CARVE(pool_states, (size_t) (P + 8) * 2);
     CARVE(pos, (size_t) (PA + 8) * 2);
     CARVE(hits, (size_t) (PA + 8) * 4);
@@ -265,6 +267,12 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(sv_gram, (size_t) max_save * NL * P * 4);
     CARVE(sv_img, (size_t) max_save * (NI + 48 + NL) * 4);
     CARVE(sv_auto, (size_t) max_save * sizeof(FcSavedRow));
+    /* P frames: reference frame planes, displacement cost tables, private chroma planes */
+    CARVE(past, inter ? npix * 2 : 0);
+    CARVE(future, 0);
+    CARVE(mc_fwd, inter ? (size_t) plevels * 1024 * 4 : 0);
+    CARVE(mc_bwd, 0);
+    CARVE(pix_chroma, inter && color ? npix / 3 * 2 * 2 : 0);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -274,12 +282,16 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
-    if (job->frame_type != FA_I_FRAME) {
-        snprintf(why, n, "the device coder does not run P/B frames yet (codec/mwfa.c); "
+    if (job->frame_type == FA_B_FRAME) {
+        snprintf(why, n, "the device coder does not run B frames yet (codec/mwfa.c:342-543); "
                          "there is no CPU fallback");
         return 0;
     }
-    if (cp->prediction && cp->p_max_level - cp->lc_min_level + 1 > 9) {
+    if (job->frame_type == FA_P_FRAME && (!job->past || cp->search_range != 16)) {
+        snprintf(why, n, "P frame without a reference frame");
+        return 0;
+    }
+    if ((cp->prediction || job->frame_type != FA_I_FRAME) && cp->p_max_level - cp->lc_min_level + 1 > 9) {
         snprintf(why, n, "prediction over more than 9 block levels is not supported by the device coder");
         return 0;
     }
@@ -431,8 +443,14 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.snap_hbm = fs.big ? (void *) (base + L.snap) : nullptr;
     /* prediction (codec/coder.c:716-745): gray frames try it from the root; a colour frame only
      * gets the second rle pool (intra prediction is never asked for its bands, :805-806) */
-    F.pred_on = cp->prediction ? 1 : 0;
-    F.pred_root = cp->prediction && !job->image->color ? 1 : 0;
+    const int inter = job->frame_type != FA_I_FRAME;
+    F.pred_on = cp->prediction || inter ? 1 : 0;
+    F.pred_root = job->image->color ? inter : (cp->prediction || inter ? 1 : 0);
+    F.search_range = (int) cp->search_range;
+    F.mv = (int16_t *) (base + L.mv);
+    F.past = (const int16_t *) (base + L.past); F.future = nullptr;
+    F.mc_fwd = (float *) (base + L.mc_fwd); F.mc_bwd = nullptr;
+    F.pix_chroma = (int16_t *) (base + L.pix_chroma);
     F.frame_type = job->frame_type;
     F.p_min = (int) cp->p_min_level; F.p_max = (int) cp->p_max_level;
     F.d_rpf_mant = (int) cp->d_rpf.mantissa_bits; F.d_dc_mant = (int) cp->d_dc_rpf.mantissa_bits;
@@ -462,12 +480,18 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     /* states a prediction attempt can displace: the nodes of a subtree from the largest
      * predicted level down to the smallest block level */
     int max_save = 0;
-    if (cp->prediction) {
+    const int inter = job->frame_type != FA_I_FRAME;
+    if (cp->prediction || inter) {
         int span = (int) cp->p_max_level - (int) cp->lc_min_level + 1;
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
-    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save);
+    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
+    /* developer aid: FIASCO_AMD_POISON=<byte> fills the slab first -- the kernel must write every
+     * cell before it reads it, whatever an earlier frame left there */
+    if (fs.base && getenv("FIASCO_AMD_POISON"))
+        (void) hipMemsetAsync(fs.base, atoi(getenv("FIASCO_AMD_POISON")), fs.L.total, S->stream);
     if (!fs.base) {
         snprintf(job->errmsg, sizeof job->errmsg, "out of HBM: frame needs %.2f GiB", fs.L.total / 1073741824.0);
         return 0;
@@ -488,6 +512,14 @@ static int stage_slot(Staged *S, FrameSlot &fs)
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
             return 0;
         }
+    if (job->frame_type != FA_I_FRAME && job->past)
+        for (int b = 0; b < bands; b++)
+            if (hipMemcpyAsync(fs.base + fs.L.past + (size_t) b * npix * 2, job->past->pixels[b], npix * 2,
+                               hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+                snprintf(job->errmsg, sizeof job->errmsg, "HIP error: reference frame upload failed");
+                slab_release(fs.base, fs.bytes); fs.base = nullptr;
+                return 0;
+            }
     if (job->ycol_carry) {                 /* [cap][2] on the host, [2][PA] on the device */
         const fa_wfa *w = job->wfa;
         fs.ycol_host.assign((size_t) 2 * fs.PA, 0);
@@ -559,7 +591,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         FrameSlot fs;
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
-        fs.big = needs_big_variant(cp, jobs[i].wfa);
+        fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
@@ -680,6 +712,8 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     const uint16_t *xs = (const uint16_t *) (host.data() + (L.x - L.tree));
     const uint16_t *ys = (const uint16_t *) (host.data() + (L.y - L.tree));
     const uint8_t *ycol = (const uint8_t *) (host.data() + (L.ycol - L.tree));
+    const int16_t *mv = (const int16_t *) (host.data() + (L.mv - L.tree));
+    const bool inter = job->frame_type != FA_I_FRAME;
     for (unsigned s = 0; s < w->basis_states; s++) w->level_of_state[s] = 0xff;   /* codec/control.c:133-173 */
     fa_wfa_remove_states(w, w->basis_states);
     for (unsigned s = w->basis_states; s < ns; s++) {
@@ -694,6 +728,12 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
             w->y_state[s * 2 + l] = FA_RANGE;
             w->y_column[s * 2 + l] = F.color ? ycol[(size_t) l * P + s] : 0;
             w->prediction[s * 2 + l] = 0;
+            if (inter) {
+                fa_mv *m = &w->mv[s * 2 + l];
+                m->type = mv[(size_t) (0 * 2 + l) * P + s]; m->fx = mv[(size_t) (1 * 2 + l) * P + s];
+                m->fy = mv[(size_t) (2 * 2 + l) * P + s]; m->bx = mv[(size_t) (3 * 2 + l) * P + s];
+                m->by = mv[(size_t) (4 * 2 + l) * P + s];
+            }
             for (int e = 0; e < 6; e++) {
                 FA_INTO(w, s, l, e) = into[(size_t) (l * 6 + e) * P + s];
                 FA_WEIGHT(w, s, l, e) = weight[(size_t) (l * 6 + e) * P + s];

@@ -93,6 +93,12 @@ typedef struct DevFrame {
     float   *sv_img;       /* [max_save][NI + 48 + NL]  image row, imgT / imgT4 columns, diagonal */
     struct FcSavedRow *sv_auto;   /* [max_save] automaton rows */
     int      max_save;
+    /* ---- motion compensation (codec/mwfa.c, codec/motion.c; P frames) ---- */
+    const int16_t *past, *future;     /* reconstructed reference frames, planes like pix16 */
+    float   *mc_fwd, *mc_bwd;         /* [p_max - p_min + 1][4 sr^2] displacement cost tables */
+    int16_t *mv;                      /* [5][2][PA] type, fx, fy, bx, by of (state, label) */
+    int16_t *pix_chroma;              /* [2][plane] chroma planes minus the luminance motion */
+    int      search_range;
     int16_t *pool_states;
     int16_t *pos;          /* state -> position in the domain pool list, -1 = not a candidate */
     int     *hits;         /* [P] edge-target histogram for the chroma domain list */
@@ -128,6 +134,7 @@ typedef struct FcSavedRow {
     float    final_d;
     uint16_t x[2], y[2];
     int16_t  pos;
+    int16_t  mv[2][5];
     uint8_t  level, dtype, ycol[2], tables;      /* tables: table rows were saved too */
 } FcSavedRow;
 

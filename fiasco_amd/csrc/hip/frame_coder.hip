@@ -103,9 +103,10 @@
 #define MIN_NORM 2e-3f
 
 enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA,
-       OP_PRED_SETUP, OP_PRED_FINISH };
+       OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
-       PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE };
+       PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO };
+enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
 #if FC_VARIANT_BIG
 #define FC_DEPTH FC_MAXDEPTH_BIG
 #else
@@ -118,8 +119,9 @@ struct Range {
     short into[MAXED + 1];
     float err, tree_bits, matrix_bits, weights_bits;
 #if FC_VARIANT_BIG
-    float nd_tree_bits, nd_weights_bits;   /* codec/cwfa.h:70-73 (the mv_* pair comes with P frames) */
+    float nd_tree_bits, nd_weights_bits, mv_tree_bits, mv_coord_bits;   /* codec/cwfa.h:68-73 */
     int   prediction;
+    short mv[5];                           /* type, fx, fy, bx, by (mv_t, codec/wfa.h:58-72) */
 #endif
 };
 
@@ -139,7 +141,8 @@ struct SFrame {
 #if FC_VARIANT_BIG
     /* prediction (codec/prediction.c:96-208): `pred` / `delta` are the arguments of the same name
      * of subdivide(); the rec_* members are what predict_range keeps of the subdivision result */
-    int   pred, delta, try_pred, pred_done, rec_states;
+    int   pred, delta, try_pred, pred_done, rec_states;     /* try_pred: 1 nd, 2 mc */
+    int   norm_first, norm_done;
     Pool  dpool0, pool_rec, dpool_rec;
     Range prange;                /* range of the residual search */
     float pred_max, pred_costs, nd_w, nd_wbits, nd_tbits;
@@ -174,7 +177,7 @@ struct __attribute__((aligned(16))) CoeffBuf {
     short cnt[FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF];
 };
 #if FC_VARIANT_BIG
-#define SNAP_POOL16 1290           /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define SNAP_POOL16 1200           /* uint4 slots for aac snapshots: depth x 2 x n16 */
 #define SNAP_TM_WORDS 2392         /* tree-model snapshots: depth x 4 x MAXLEVEL words */
 #else
 #define SNAP_POOL16 840
@@ -220,6 +223,8 @@ struct Sh {
     int      nslot;                /* aac snapshot slots per depth: 2, or 5 with prediction */
     uint4   *snap_tm_p;            /* tree-model snapshots: snap_tm, or HBM with prediction */
     int      pred_active, pred_lo, pred_rec;   /* a residual search is running; displaced ids */
+    struct { int fx, fy; float bits, costs; } mc;      /* result of OP_MC_SEARCH */
+    unsigned long long mcred[B / 64];
     unsigned pred_saved[FC_MAXSAVE / 32];      /* their table rows are in the save area */
 #endif
     uint4    snap_pool[SNAP_POOL16];
@@ -663,6 +668,9 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
     const int16_t *plane = F.pix16 + (size_t) sh.band * F.plane;
+#if FC_VARIANT_BIG
+    if (F.frame_type && sh.band) plane = F.pix_chroma + (size_t) (sh.band - 1) * F.plane;
+#endif
     {   /* all pixel loads of the lane in flight: unconditional loads at clamped coordinates,
          * the outside of the image is zeroed afterwards (codec/subdivide.c:504-541) */
         constexpr int NIT = FC_PIXELS / B;
@@ -725,6 +733,7 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
 
 #if FC_VARIANT_BIG
 __device__ void pred_save_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s);
+__device__ void subtract_mc_dev(DevFrame &__restrict__ F, Sh &__restrict__ sh);
 #endif
 
 /* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
@@ -930,6 +939,9 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     const int states = sh.states, to = states - 1;
     Pool &m = sh.pool;
     const int maxd = F.chroma_max;
+#if FC_VARIANT_BIG
+    if (F.frame_type) { subtract_mc_dev(F, sh); __syncthreads(); }     /* codec/coder.c:798-799 */
+#endif
     if (tid == 0) { sh.lc_min = F.ML; sh.ystates = states; }
     if (maxd < (int) m.n) {
         /* histogram in HBM with device-scope atomics; read back past the L1 */
@@ -1061,10 +1073,141 @@ __device__ void swap_model_sets(Sh &sh)
     }
 }
 
+/* ---- motion compensation (codec/mwfa.c; P frames, full-pixel vectors) ---- */
+
+/* MPEG's vector-component code lengths (mv_code_table[][1], codec/mwfa.c:40-50) */
+__device__ __forceinline__ float mv_bits(int v, int sr)
+{
+    /* lengths 11 11 11 11 11 11 10 10 10 8 8 8 7 5 4 3 | 1 | mirrored: one nibble per code */
+    const unsigned long long len = 0xbbbbbbaaa8887543ull;
+    const int i = v + sr;
+    if (i == 16) return 1.0f;
+    return (float) ((len >> (4 * (i < 16 ? 15 - i : i - 17))) & 15u);
+}
+
+/* fill_norms_table (codec/mwfa.c:545-602): squared norm of original - displaced reference block
+ * for every displacement of the search window, 0 outside the frame.  One displacement per lane
+ * and pass; per displacement the pixels are summed in raster order like mcpe_norm (:658-684). */
+__device__ void fill_norms(const DevFrame &__restrict__ F, int x0, int y0, int level)
+{
+    const int tid = threadIdx.x, sr = F.search_range, n = 4 * sr * sr;
+    const int bw = (int) width_of_level(level), bh = (int) height_of_level(level), W = F.width, H = F.height;
+    float *dst = F.mc_fwd + (size_t) (level - F.p_min) * n;
+    const int16_t *orig = F.pix16 + (size_t) y0 * W + x0;
+    for (int idx = tid; idx < n; idx += B) {
+        const int mx = idx % (2 * sr) - sr, my = idx / (2 * sr) - sr;
+        float norm = 0.0f;
+        if (!(x0 + mx < 0 || x0 + mx + bw > W || y0 + my < 0 || y0 + my + bh > H)) {
+            const int16_t *ref = F.past + (size_t) (y0 + my) * W + (x0 + mx);
+            for (int y = 0; y < bh; y++)
+                for (int x = 0; x < bw; x++) {
+                    const int q = (int) (short) (orig[(size_t) y * W + x] - ref[(size_t) y * W + x]) / 16;
+                    norm += (float) (q * q);
+                }
+        }
+        dst[idx] = norm;
+    }
+}
+
+/* after a child of a motion compensated node: table of the child's level if the child was not
+ * searched (subdivide.c:311-315), then update_norms_table (prediction.c:229-254); `first`
+ * stands for the clear_norms_table at the node's entry (0 + x == x) */
+__device__ __noinline__ void op_norms(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int first,
+                                      int fill_level, int xy)
+{
+    const int tid = threadIdx.x, n = 4 * F.search_range * F.search_range;
+    if (fill_level >= 0) {
+        fill_norms(F, xy & 0xffff, xy >> 16, fill_level);
+        __syncthreads();
+    }
+    if (level > F.p_min) {
+        float *dst = F.mc_fwd + (size_t) (level - F.p_min) * n;
+        const float *src = dst - n;
+        for (int i = tid; i < n; i += B) dst[i] = first ? 0.0f + src[i] : dst[i] + src[i];
+    }
+}
+
+/* find_P_frame_mc / find_best_mv (codec/mwfa.c:302-340,686-798): first displacement, in scan
+ * order, with the smallest costs norm + (bits_x + bits_y) * price */
+__device__ __noinline__ void op_mc_search(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int xy, int fill)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sr = F.search_range, n = 4 * sr * sr;
+    const int x0 = xy & 0xffff, y0 = xy >> 16;
+    const int bw = (int) width_of_level(level), bh = (int) height_of_level(level), W = F.width, H = F.height;
+    const float price = sh.st[sh.sp].price;
+    if (fill & 1) { fill_norms(F, x0, y0, level); __syncthreads(); }
+    if (fill & 2) {
+        /* a node above p_min_level whose children were never visited (its level is not above the
+         * smallest block level, which a colour stream ratchets upwards, codec/coder.c:785-797):
+         * the table is what clear_norms_table left at the entry (prediction.c:210-227) */
+        float *t = F.mc_fwd + (size_t) (level - F.p_min) * n;
+        for (int i = tid; i < n; i += B) t[i] = 0.0f;
+        __syncthreads();
+    }
+    const float *norms = F.mc_fwd + (size_t) (level - F.p_min) * n;
+    unsigned long long best = ~0ull;
+    for (int idx = tid; idx < n; idx += B) {
+        const int mx = idx % (2 * sr) - sr, my = idx / (2 * sr) - sr;
+        if (x0 + mx >= 0 && y0 + my >= 0 && x0 + mx + bw <= W && y0 + my + bh <= H) {
+            const float costs = norms[idx] + (mv_bits(mx, sr) + mv_bits(my, sr)) * price;
+            /* costs >= 0: the float's bit pattern orders like the value */
+            const unsigned long long key = ((unsigned long long) __float_as_uint(costs) << 32) | (unsigned) idx;
+            if (key < best) best = key;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(best, o);
+        if (t < best) best = t;
+    }
+    if (lane == 0) sh.mcred[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long g = sh.mcred[0];
+        for (int i = 1; i < B / 64; i++) if (sh.mcred[i] < g) g = sh.mcred[i];
+        int fx = 0, fy = 0;
+        float costs = MAXCOSTS;
+        if (g != ~0ull && __uint_as_float((unsigned) (g >> 32)) < MAXCOSTS) {
+            const int idx = (int) (g & 0xffffffffu);
+            fx = idx % (2 * sr) - sr; fy = idx / (2 * sr) - sr;
+            costs = __uint_as_float((unsigned) (g >> 32));
+        }
+        sh.mc.fx = fx; sh.mc.fy = fy; sh.mc.costs = costs;
+        sh.mc.bits = mv_bits(fx, sr) + mv_bits(fy, sr);
+    }
+}
+
+/* subtract_mc (codec/mwfa.c:156-300): private chroma planes = original chroma - luminance motion
+ * compensation with the vector components rounded to even; called once, at the first chroma band */
+__device__ void subtract_mc_dev(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    const int tid = threadIdx.x, W = F.width;
+    const size_t npix = (size_t) F.plane;
+    for (size_t i = tid; i < 2 * npix; i += B) F.pix_chroma[i] = F.pix16[npix + i];
+    __syncthreads();
+    for (int s = F.basis_states; s < sh.states; s++)                 /* blocks do not overlap */
+        for (int l = 0; l < 2; l++) {
+            if (F.mv[(0 * 2 + l) * F.PA + s] != MV_FORWARD) continue;       /* uniform */
+            const int lv = (int) F.level_of_state[s] - 1;
+            const int bw = (int) width_of_level(lv), bh = (int) height_of_level(lv);
+            const int x0 = F.x[l * F.PA + s], y0 = F.y[l * F.PA + s];
+            const int fx = (F.mv[(1 * 2 + l) * F.PA + s] / 2) * 2, fy = (F.mv[(2 * 2 + l) * F.PA + s] / 2) * 2;
+            for (int b = 0; b < 2; b++) {
+                int16_t *o = F.pix_chroma + (size_t) b * npix + (size_t) y0 * W + x0;
+                const int16_t *r = F.past + (size_t) (b + 1) * npix + (size_t) (y0 + fy) * W + (x0 + fx);
+                for (int i = tid; i < bw * bh; i += B) {
+                    const int x = i % bw, y = i / bw;
+                    o[(size_t) y * W + x] = (int16_t) (o[(size_t) y * W + x] - r[(size_t) y * W + x]);
+                }
+            }
+        }
+}
+
 /* a0 = level of the range, a1 = its address in the block; the frame on top of the stack holds
  * the DC weight (nd_w).  States [fr.states, fr.rec_states) are the ones the subdivision made. */
 __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int address)
 {
+    const bool mc = sh.st[sh.sp].try_pred == 2;
     const int tid = threadIdx.x, il = F.images_level;
     SFrame &fr = sh.st[sh.sp];
     const int size = 1 << level, npx = 1 << F.lc_max;
@@ -1082,9 +1225,29 @@ __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restr
         }
         r.final_d = F.final_d[s]; r.level = F.level_of_state[s]; r.dtype = F.domain_type[s];
         r.pos = F.pos[s]; r.tables = 0;
+        if (F.frame_type)
+            for (int l = 0; l < 2; l++)
+                for (int k = 0; k < 5; k++) r.mv[l][k] = F.mv[(k * 2 + l) * F.PA + s];
     }
     /* residual: range pixels + w, w = - weight * <image of state 0 at level 0> (:417-427) */
-    {
+    if (mc) {
+        /* motion compensated prediction error of the range, bintree order, / 16 truncated
+         * (get_mcpe + cut_to_bintree, codec/mwfa.c:610-656, codec/subdivide.c:504-541) */
+        const Range &rg = fr.rg;
+        const int W = F.width, fx = fr.prange.mv[1], fy = fr.prange.mv[2];
+        const int16_t *orig = F.pix16 + (size_t) rg.y * W + rg.x;
+        const int16_t *ref = F.past + (size_t) (rg.y + fy) * W + (rg.x + fx);
+        for (int i = tid; i < size; i += B) {
+            unsigned xo = 0, yo = 0;
+#pragma unroll
+            for (int b = 0; b < 13; b++) {
+                yo |= ((i >> (2 * b)) & 1u) << b;
+                xo |= ((i >> (2 * b + 1)) & 1u) << b;
+            }
+            const short d = (short) (orig[(size_t) yo * W + xo] - ref[(size_t) yo * W + xo]);
+            sh.pixels[i] = (float) ((int) d / 16);
+        }
+    } else {
         const float w = -fr.nd_w * F.img[0];
         float v[FC_PIXELS / B];
 #pragma unroll
@@ -1174,6 +1337,9 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
             F.final_d[s] = r.final_d; F.level_of_state[s] = r.level; F.domain_type[s] = r.dtype;
             F.pos[s] = r.pos;
             if (r.pos >= 0) F.pool_states[r.pos] = (short) s;
+            if (F.frame_type)
+                for (int l = 0; l < 2; l++)
+                    for (int k = 0; k < 5; k++) F.mv[(k * 2 + l) * F.PA + s] = r.mv[l][k];
         }
         for (int idx = 0; idx < fr.rec_states - fr.states && idx < F.max_save; idx++) {
             if (!((sh.pred_saved[idx >> 5] >> (idx & 31)) & 1u)) continue;      /* uniform */
@@ -1363,6 +1529,10 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
             for (int e = 0; ch.into[e] != NOEDGE; e++) if (ch.into[e] == fr.ny[l]) yc = 1;
             F.ycol[l * F.PA + s] = (uint8_t) yc;
         }
+#if FC_VARIANT_BIG
+        if (F.frame_type)                              /* wfa->mv_tree, codec/subdivide.c:592 */
+            for (int k = 0; k < 5; k++) F.mv[(k * 2 + l) * F.PA + s] = ch.mv[k];
+#endif
     }
     F.final_d[s] = final_distribution_dev(F, s);
     F.level_of_state[s] = (uint8_t) fr.rrange.level;
@@ -1383,6 +1553,9 @@ __device__ int append_join_state(DevFrame &__restrict__ F, Sh &__restrict__ sh, 
     F.level_of_state[s] = (uint8_t) level;
     F.domain_type[s] = 0;
     F.pos[s] = -1;
+#if FC_VARIANT_BIG
+    if (F.frame_type) for (int k = 0; k < 10; k++) F.mv[k * F.PA + s] = 0;
+#endif
     sh.states++;
     if (sh.states >= F.limit_states) { sh.failed = FC_ERR_STATES; return 0; }
     return 1;
@@ -1399,7 +1572,8 @@ __device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_s
     r.y_state = y_state;
     r.phase = PH_ENTER;
 #if FC_VARIANT_BIG
-    r.rg.nd_tree_bits = r.rg.nd_weights_bits = 0; r.rg.prediction = 0;
+    r.rg.nd_tree_bits = r.rg.nd_weights_bits = r.rg.mv_tree_bits = r.rg.mv_coord_bits = 0; r.rg.prediction = 0;
+    for (int i = 0; i < 5; i++) r.rg.mv[i] = 0;
     r.pred = sh.band == 0 ? F.pred_root : 0;     /* codec/coder.c:743-745,805-806 */
     r.delta = 0;
 #endif
@@ -1474,9 +1648,15 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             fr.price = sh.par.price;
             if (sh.band) fr.price *= sh.par.chroma_decrease;
 #if FC_VARIANT_BIG
-            /* try_nd (codec/subdivide.c:149-151); P/B frames (try_mc) are not on the device yet */
-            fr.try_pred = fr.pred && F.frame_type == 0 && rg.level >= F.p_min && rg.level <= F.p_max;
+            /* try_nd / try_mc (codec/subdivide.c:141-154) */
+            fr.try_pred = 0;
+            if (fr.pred && rg.level >= F.p_min && rg.level <= F.p_max) {
+                if (F.frame_type == 0) fr.try_pred = 1;
+                else if (rg.x + (int) width_of_level(rg.level) <= sh.par.width
+                         && rg.y + (int) height_of_level(rg.level) <= sh.par.height) fr.try_pred = 2;
+            }
             fr.pred_done = 0;
+            fr.norm_first = 1; fr.norm_done = 0;     /* clear_norms_table, folded into the first update */
 #endif
             fr.phase = PH_AFTER_INIT;
             if (rg.level == sh.par.lc_max) {
@@ -1520,6 +1700,8 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.lrange.weights_bits = 0;
 #if FC_VARIANT_BIG
                 fr.lrange.nd_tree_bits = 0; fr.lrange.nd_weights_bits = 0; fr.lrange.prediction = 0;
+                fr.lrange.mv_tree_bits = fr.try_pred == 2 ? 1.0f : 0.0f;   /* mc allowed but not used */
+                fr.lrange.mv_coord_bits = 0;
 #endif
                 sh.op = OP_APPROX;
                 return;
@@ -1546,7 +1728,8 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
                 z.err = z.tree_bits = z.matrix_bits = z.weights_bits = 0;
 #if FC_VARIANT_BIG
-                z.nd_tree_bits = z.nd_weights_bits = 0; z.prediction = 0;
+                z.nd_tree_bits = z.nd_weights_bits = z.mv_tree_bits = z.mv_coord_bits = 0; z.prediction = 0;
+                for (int i = 0; i < 5; i++) z.mv[i] = 0;
 #endif
                 fr.child[0] = z; fr.child[1] = z;
                 fr.rrange = rg;
@@ -1555,12 +1738,15 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.rrange.weights_bits = 0;
                 fr.rrange.err = 0;
 #if FC_VARIANT_BIG
-                /* codec/subdivide.c:259-271 (the mv terms are zero in an intra frame) */
-                fr.rrange.nd_tree_bits = fr.try_pred ? tree_bits_dev(sh, ML, 1, rg.level, 1) : 0.0f;
+                /* codec/subdivide.c:257-271 */
+                fr.rrange.mv_tree_bits = fr.try_pred == 2 ? 1.0f : 0.0f;
+                fr.rrange.mv_coord_bits = 0;
+                fr.rrange.nd_tree_bits = fr.try_pred == 1 ? tree_bits_dev(sh, ML, 1, rg.level, 1) : 0.0f;
                 fr.rrange.nd_weights_bits = 0;
                 fr.rrange.prediction = 0;
                 fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits
-                             + 0.0f + 0.0f + fr.rrange.nd_tree_bits + fr.rrange.nd_weights_bits) * fr.price;
+                             + fr.rrange.mv_tree_bits + fr.rrange.mv_coord_bits + fr.rrange.nd_tree_bits
+                             + fr.rrange.nd_weights_bits) * fr.price;
 #else
                 fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits) * fr.price;
 #endif
@@ -1613,6 +1799,19 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         case PH_CHILD_RET: {
             const int label = fr.label;
             float lim = fr.lincomb > fr.max_costs ? fr.max_costs : fr.lincomb;
+#if FC_VARIANT_BIG
+            if (fr.try_pred == 2 && !fr.norm_done) {
+                /* a child that was not searched gets its displacement table here
+                 * (subdivide.c:311-315); then update_norms_table (:317-318) */
+                const Range &c0 = fr.child[label];
+                sh.op = OP_NORMS; sh.a0 = fr.rg.level; sh.a1 = fr.norm_first;
+                sh.a2 = (fr.ret < 0 && c0.level >= F.p_min) ? c0.level : -1;
+                sh.a3 = c0.x | (c0.y << 16);
+                fr.norm_first = 0; fr.norm_done = 1;
+                return;
+            }
+            fr.norm_done = 0;
+#endif
             if (fr.ret >= 0) fr.subdiv += fr.ret;
             if (fr.subdiv >= lim) {
                 fr.subdiv = MAXCOSTS;
@@ -1625,6 +1824,8 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             fr.rrange.matrix_bits  += ch.matrix_bits;
             fr.rrange.weights_bits += ch.weights_bits;
 #if FC_VARIANT_BIG
+            fr.rrange.mv_tree_bits    += ch.mv_tree_bits;
+            fr.rrange.mv_coord_bits   += ch.mv_coord_bits;
             fr.rrange.nd_weights_bits += ch.nd_weights_bits;
             fr.rrange.nd_tree_bits    += ch.nd_tree_bits;
             tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
@@ -1709,6 +1910,12 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             snap_load(F, sh, sh.sp, 0); snap_load_d(sh, sh.sp, 2); tm_load(sh, sh.sp, ML, 0);
             sh.states = fr.states;
             if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
+            if (fr.try_pred == 2) {          /* mc_prediction, prediction.c:262-289 */
+                sh.op = OP_MC_SEARCH; sh.a0 = rg.level; sh.a1 = rg.x | (rg.y << 16);
+                sh.a2 = (rg.level == F.p_min ? 1 : 0) | (rg.level > F.p_min && fr.norm_first ? 2 : 0);
+                fr.phase = PH_PRED_MC2;
+                return;
+            }
             {   /* the range's DC part in the DC format of the normal model */
                 const float x = rg.level > il ? sh.par.ipis[(size_t) rg.image * P]
                                               : (rg.level == il ? sh.par.d5 : sh.par.d4)[(size_t) rg.address * P];
@@ -1720,10 +1927,22 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.nd_wbits = (float) (0.0 - log2((double) (cnt / (float) sh.cb.tot[0])));
             }
             fr.pred_costs = fr.price * (fr.nd_wbits + fr.nd_tbits);
-            if (fr.pred_costs < maxc) {
+            fr.phase = PH_PRED_GO;
+            break;
+        }
+        case PH_PRED_MC2: {                  /* find_P_frame_mc done: vector in sh.mc (prediction.c:282-289) */
+            fr.prange = fr.rg;
+            fr.prange.mv[0] = MV_FORWARD; fr.prange.mv[1] = (short) sh.mc.fx; fr.prange.mv[2] = (short) sh.mc.fy;
+            fr.prange.mv_tree_bits = 1; fr.prange.mv_coord_bits = sh.mc.bits;
+            fr.pred_costs = (fr.prange.mv_tree_bits + fr.prange.mv_coord_bits) * fr.price;
+            fr.phase = PH_PRED_GO;
+            break;
+        }
+        case PH_PRED_GO: {
+            if (fr.pred_costs < fr.pred_max) {
                 if (fr.rec_states - fr.states > F.max_save || sh.sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; }
                 else {
-                    sh.op = OP_PRED_SETUP; sh.a0 = rg.level; sh.a1 = rg.address;
+                    sh.op = OP_PRED_SETUP; sh.a0 = fr.rg.level; sh.a1 = fr.rg.address;
                     fr.phase = PH_PRED_RECURSE;
                     return;
                 }
@@ -1732,15 +1951,16 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
             snap_load(F, sh, sh.sp, 3); snap_load_d(sh, sh.sp, 4); tm_load(sh, sh.sp, ML, 1);
             sh.states = fr.rec_states;
-            rg.prediction = 0;
+            fr.rg.prediction = 0;
             fr.phase = PH_DECIDE;
             break;
         }
         case PH_PRED_RECURSE: {              /* subdivide (max_costs - costs, ..., NO, YES), :432-456 */
             SFrame &cf = sh.st[sh.sp + 1];
             cf.rg = fr.rg;
+            if (fr.try_pred == 2) for (int i = 0; i < 5; i++) cf.rg.mv[i] = fr.prange.mv[i];
             cf.rg.tree_bits = cf.rg.matrix_bits = cf.rg.weights_bits = 0;
-            cf.rg.nd_tree_bits = cf.rg.nd_weights_bits = 0;
+            cf.rg.nd_tree_bits = cf.rg.nd_weights_bits = cf.rg.mv_tree_bits = cf.rg.mv_coord_bits = 0;
             cf.rg.image = 0; cf.rg.address = 0;
             cf.y_state = fr.y_state;
             cf.max_costs = fr.pred_max - fr.pred_costs;
@@ -1752,7 +1972,8 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         }
         case PH_PRED_RET: {
             const float costs = fr.pred_costs + fr.ret;
-            const int keep = !sh.failed && costs < fr.pred_max && fr.prange.tree != RANGE_;
+            /* nd: only a subdivided residual counts (:460); mc: any (:329) */
+            const int keep = !sh.failed && costs < fr.pred_max && (fr.try_pred == 2 || fr.prange.tree != RANGE_);
             fr.pred_costs = costs;
             sh.op = OP_PRED_FINISH; sh.a0 = keep;
             fr.phase = PH_PRED_DONE;
@@ -1763,15 +1984,20 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             Range &rg = fr.rg;
             if (fr.label) {                  /* use the prediction, prediction.c:460-485,152-180 */
                 const int img = rg.image, adr = rg.address;
+                const float mvt = fr.try_pred == 2 ? 1.0f : 0.0f, mvc = fr.try_pred == 2 ? sh.mc.bits : 0.0f;
                 rg = fr.prange;
                 rg.image = img; rg.address = adr;
-                rg.nd_tree_bits += fr.nd_tbits;
-                rg.nd_weights_bits += fr.nd_wbits;
-                rg.into[0] = 0; rg.weight[0] = fr.nd_w; rg.into[1] = NOEDGE;
+                if (fr.try_pred == 2) {      /* prediction.c:333-340 */
+                    rg.mv_coord_bits = mvc; rg.mv_tree_bits = mvt;
+                } else {
+                    rg.nd_tree_bits += fr.nd_tbits;
+                    rg.nd_weights_bits += fr.nd_wbits;
+                    rg.into[0] = 0; rg.weight[0] = fr.nd_w; rg.into[1] = NOEDGE;
+                }
                 rg.prediction = 1;
                 if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
-                fr.ret = (rg.tree_bits + rg.matrix_bits + rg.weights_bits + 0.0f + 0.0f + rg.nd_tree_bits
-                          + rg.nd_weights_bits) * fr.price + rg.err;
+                fr.ret = (rg.tree_bits + rg.matrix_bits + rg.weights_bits + rg.mv_tree_bits + rg.mv_coord_bits
+                          + rg.nd_tree_bits + rg.nd_weights_bits) * fr.price + rg.err;
                 goto pop;
             }
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
@@ -2002,6 +2228,8 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
 #if FC_VARIANT_BIG
         case OP_PRED_SETUP:  op_pred_setup(F, sh, sh.a0, sh.a1); break;
         case OP_PRED_FINISH: op_pred_finish(F, sh, sh.a0); break;
+        case OP_NORMS:       op_norms(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
+        case OP_MC_SEARCH:   op_mc_search(F, sh, sh.a0, sh.a1, sh.a2); break;
 #endif
         default: break;                      /* OP_NOP */
         }

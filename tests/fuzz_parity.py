@@ -55,7 +55,7 @@ def random_options(rng, lib=None):
     cq = float(rng.choice([1.0, 2.0, 3.5])); cd = int(rng.choice([1, 5, 40, 63]))
     pred = (0, 6, 10)
     if os.environ.get("FUZZ_PRED") == "1" and rng.integers(0, 4):     # intra prediction (ND)
-        plo = int(rng.integers(4, 11))
+        plo = int(rng.integers(6, 11))
         pred = (1, plo, int(rng.integers(plo, 13)))
     spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred)
     return spec

@@ -269,9 +269,9 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(sv_auto, (size_t) max_save * sizeof(FcSavedRow));
     /* P frames: reference frame planes, displacement cost tables, private chroma planes */
     CARVE(past, inter ? npix * 2 : 0);
-    CARVE(future, 0);
+    CARVE(future, inter == 2 ? npix * 2 : 0);
     CARVE(mc_fwd, inter ? (size_t) plevels * 1024 * 4 : 0);
-    CARVE(mc_bwd, 0);
+    CARVE(mc_bwd, inter ? (size_t) plevels * 1024 * 4 : 0);
     CARVE(pix_chroma, inter && color ? npix / 3 * 2 * 2 : 0);
     CARVE(pix16, npix * 2);
 #undef CARVE
@@ -282,13 +282,11 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
-    if (job->frame_type == FA_B_FRAME) {
-        snprintf(why, n, "the device coder does not run B frames yet (codec/mwfa.c:342-543); "
-                         "there is no CPU fallback");
-        return 0;
-    }
-    if (job->frame_type == FA_P_FRAME && (!job->past || cp->search_range != 16)) {
-        snprintf(why, n, "P frame without a reference frame");
+    if (job->frame_type != FA_I_FRAME
+        && (!job->past || (job->frame_type == FA_B_FRAME && !job->future) || cp->search_range != 16)) {
+        /* e.g. an I frame as the future reference of B frames: the reference coder dereferences
+         * a null frame at its first motion search */
+        snprintf(why, n, "Motion search without a reference frame (frame pattern).");
         return 0;
     }
     if ((cp->prediction || job->frame_type != FA_I_FRAME) && cp->p_max_level - cp->lc_min_level + 1 > 9) {
@@ -448,8 +446,8 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pred_root = job->image->color ? inter : (cp->prediction || inter ? 1 : 0);
     F.search_range = (int) cp->search_range;
     F.mv = (int16_t *) (base + L.mv);
-    F.past = (const int16_t *) (base + L.past); F.future = nullptr;
-    F.mc_fwd = (float *) (base + L.mc_fwd); F.mc_bwd = nullptr;
+    F.past = (const int16_t *) (base + L.past); F.future = (const int16_t *) (base + L.future);
+    F.mc_fwd = (float *) (base + L.mc_fwd); F.mc_bwd = inter ? (float *) (base + L.mc_bwd) : nullptr;
     F.pix_chroma = (int16_t *) (base + L.pix_chroma);
     F.frame_type = job->frame_type;
     F.p_min = (int) cp->p_min_level; F.p_max = (int) cp->p_max_level;
@@ -480,7 +478,7 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     /* states a prediction attempt can displace: the nodes of a subtree from the largest
      * predicted level down to the smallest block level */
     int max_save = 0;
-    const int inter = job->frame_type != FA_I_FRAME;
+    const int inter = job->frame_type;                 /* 0 I, 1 P, 2 B */
     if (cp->prediction || inter) {
         int span = (int) cp->p_max_level - (int) cp->lc_min_level + 1;
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
@@ -515,6 +513,14 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     if (job->frame_type != FA_I_FRAME && job->past)
         for (int b = 0; b < bands; b++)
             if (hipMemcpyAsync(fs.base + fs.L.past + (size_t) b * npix * 2, job->past->pixels[b], npix * 2,
+                               hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+                snprintf(job->errmsg, sizeof job->errmsg, "HIP error: reference frame upload failed");
+                slab_release(fs.base, fs.bytes); fs.base = nullptr;
+                return 0;
+            }
+    if (job->frame_type == FA_B_FRAME && job->future)
+        for (int b = 0; b < bands; b++)
+            if (hipMemcpyAsync(fs.base + fs.L.future + (size_t) b * npix * 2, job->future->pixels[b], npix * 2,
                                hipMemcpyHostToDevice, S->stream) != hipSuccess) {
                 snprintf(job->errmsg, sizeof job->errmsg, "HIP error: reference frame upload failed");
                 slab_release(fs.base, fs.bytes); fs.base = nullptr;

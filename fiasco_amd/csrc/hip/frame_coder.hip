@@ -223,7 +223,7 @@ struct Sh {
     int      nslot;                /* aac snapshot slots per depth: 2, or 5 with prediction */
     uint4   *snap_tm_p;            /* tree-model snapshots: snap_tm, or HBM with prediction */
     int      pred_active, pred_lo, pred_rec;   /* a residual search is running; displaced ids */
-    struct { int fx, fy; float bits, costs; } mc;      /* result of OP_MC_SEARCH */
+    struct { int type, fx, fy, bx, by; float bits, tree_bits; } mc;      /* result of OP_MC_SEARCH */
     unsigned long long mcred[B / 64];
     unsigned pred_saved[FC_MAXSAVE / 32];      /* their table rows are in the save area */
 #endif
@@ -1093,10 +1093,12 @@ __device__ void fill_norms(const DevFrame &__restrict__ F, int x0, int y0, int l
     const int tid = threadIdx.x, sr = F.search_range, n = 4 * sr * sr;
     const int bw = (int) width_of_level(level), bh = (int) height_of_level(level), W = F.width, H = F.height;
     float *dst = F.mc_fwd + (size_t) (level - F.p_min) * n;
+    float *dstb = F.mc_bwd + (size_t) (level - F.p_min) * n;
     const int16_t *orig = F.pix16 + (size_t) y0 * W + x0;
+    const bool bframe = F.frame_type == 2;
     for (int idx = tid; idx < n; idx += B) {
         const int mx = idx % (2 * sr) - sr, my = idx / (2 * sr) - sr;
-        float norm = 0.0f;
+        float norm = 0.0f, normb = 0.0f;
         if (!(x0 + mx < 0 || x0 + mx + bw > W || y0 + my < 0 || y0 + my + bh > H)) {
             const int16_t *ref = F.past + (size_t) (y0 + my) * W + (x0 + mx);
             for (int y = 0; y < bh; y++)
@@ -1104,8 +1106,20 @@ __device__ void fill_norms(const DevFrame &__restrict__ F, int x0, int y0, int l
                     const int q = (int) (short) (orig[(size_t) y * W + x] - ref[(size_t) y * W + x]) / 16;
                     norm += (float) (q * q);
                 }
+            if (bframe) {
+                const int16_t *reb = F.future + (size_t) (y0 + my) * W + (x0 + mx);
+                for (int y = 0; y < bh; y++)
+                    for (int x = 0; x < bw; x++) {
+                        const int q = (int) (short) (orig[(size_t) y * W + x] - reb[(size_t) y * W + x]) / 16;
+                        normb += (float) (q * q);
+                    }
+            }
+            dst[idx] = norm;
+            if (bframe) dstb[idx] = normb;
+        } else {
+            dst[idx] = 0.0f;                 /* both tables, whatever the frame type (:576-577) */
+            if (F.mc_bwd) dstb[idx] = 0.0f;
         }
-        dst[idx] = norm;
     }
 }
 
@@ -1124,27 +1138,24 @@ __device__ __noinline__ void op_norms(DevFrame &__restrict__ F, Sh &__restrict__
         float *dst = F.mc_fwd + (size_t) (level - F.p_min) * n;
         const float *src = dst - n;
         for (int i = tid; i < n; i += B) dst[i] = first ? 0.0f + src[i] : dst[i] + src[i];
+        if (F.frame_type == 2) {
+            float *dstb = F.mc_bwd + (size_t) (level - F.p_min) * n;
+            const float *srcb = dstb - n;
+            for (int i = tid; i < n; i += B) dstb[i] = first ? 0.0f + srcb[i] : dstb[i] + srcb[i];
+        } else if (first && F.mc_bwd) {      /* clear_norms_table clears both */
+            float *dstb = F.mc_bwd + (size_t) (level - F.p_min) * n;
+            for (int i = tid; i < n; i += B) dstb[i] = 0.0f;
+        }
     }
 }
 
-/* find_P_frame_mc / find_best_mv (codec/mwfa.c:302-340,686-798): first displacement, in scan
- * order, with the smallest costs norm + (bits_x + bits_y) * price */
-__device__ __noinline__ void op_mc_search(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int xy, int fill)
+/* find_best_mv (codec/mwfa.c:686-798): first displacement, in scan order, with the smallest
+ * costs norm + (bits_x + bits_y) * price.  All lanes; result on lane 0. */
+__device__ void best_mv(const DevFrame &__restrict__ F, Sh &__restrict__ sh, const float *norms, int x0, int y0,
+                        int bw, int bh, float price, int &mx_out, int &my_out, float &bits, float &costs_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sr = F.search_range, n = 4 * sr * sr;
-    const int x0 = xy & 0xffff, y0 = xy >> 16;
-    const int bw = (int) width_of_level(level), bh = (int) height_of_level(level), W = F.width, H = F.height;
-    const float price = sh.st[sh.sp].price;
-    if (fill & 1) { fill_norms(F, x0, y0, level); __syncthreads(); }
-    if (fill & 2) {
-        /* a node above p_min_level whose children were never visited (its level is not above the
-         * smallest block level, which a colour stream ratchets upwards, codec/coder.c:785-797):
-         * the table is what clear_norms_table left at the entry (prediction.c:210-227) */
-        float *t = F.mc_fwd + (size_t) (level - F.p_min) * n;
-        for (int i = tid; i < n; i += B) t[i] = 0.0f;
-        __syncthreads();
-    }
-    const float *norms = F.mc_fwd + (size_t) (level - F.p_min) * n;
+    const int W = F.width, H = F.height;
     unsigned long long best = ~0ull;
     for (int idx = tid; idx < n; idx += B) {
         const int mx = idx % (2 * sr) - sr, my = idx / (2 * sr) - sr;
@@ -1160,20 +1171,91 @@ __device__ __noinline__ void op_mc_search(DevFrame &__restrict__ F, Sh &__restri
         unsigned long long t = __shfl_xor(best, o);
         if (t < best) best = t;
     }
+    __syncthreads();                         /* sh.mcred of an earlier call has been read */
     if (lane == 0) sh.mcred[wave] = best;
     __syncthreads();
+    unsigned long long g = sh.mcred[0];
+    for (int i = 1; i < B / 64; i++) if (sh.mcred[i] < g) g = sh.mcred[i];
+    mx_out = my_out = 0;
+    costs_out = MAXCOSTS;
+    if (g != ~0ull && __uint_as_float((unsigned) (g >> 32)) < MAXCOSTS) {
+        const int idx = (int) (g & 0xffffffffu);
+        mx_out = idx % (2 * sr) - sr; my_out = idx / (2 * sr) - sr;
+        costs_out = __uint_as_float((unsigned) (g >> 32));
+    }
+    bits = mv_bits(mx_out, sr) + mv_bits(my_out, sr);
+}
+
+/* find_P_frame_mc / find_B_frame_mc (codec/mwfa.c:302-543; cross_B_search is never set: the
+ * reference copies it from half_pixel_prediction, codec/coder.c:359, and half-pixel vectors are
+ * refused by the host).  Result in sh.mc. */
+__device__ __noinline__ void op_mc_search(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int xy, int fill)
+{
+    const int tid = threadIdx.x, sr = F.search_range, n = 4 * sr * sr;
+    const int x0 = xy & 0xffff, y0 = xy >> 16;
+    const int bw = (int) width_of_level(level), bh = (int) height_of_level(level), W = F.width;
+    const float price = sh.st[sh.sp].price;
+    if (fill & 1) { fill_norms(F, x0, y0, level); __syncthreads(); }
+    if (fill & 2) {
+        /* a node above p_min_level whose children were never visited (its level is not above the
+         * smallest block level, which a colour stream ratchets upwards, codec/coder.c:785-797):
+         * the table is what clear_norms_table left at the entry (prediction.c:210-227) */
+        float *t = F.mc_fwd + (size_t) (level - F.p_min) * n;
+        for (int i = tid; i < n; i += B) t[i] = 0.0f;
+        if (F.mc_bwd) { t = F.mc_bwd + (size_t) (level - F.p_min) * n; for (int i = tid; i < n; i += B) t[i] = 0.0f; }
+        __syncthreads();
+    }
+    int fx, fy, bx = 0, by = 0;
+    float fbits, bbits = 0, fcosts, bcosts = 0;
+    best_mv(F, sh, F.mc_fwd + (size_t) (level - F.p_min) * n, x0, y0, bw, bh, price, fx, fy, fbits, fcosts);
+    if (F.frame_type != 2) {
+        if (tid == 0) { sh.mc.type = MV_FORWARD; sh.mc.fx = fx; sh.mc.fy = fy; sh.mc.bx = sh.mc.by = 0;
+                        sh.mc.bits = fbits; sh.mc.tree_bits = 1.0f; }
+        return;
+    }
+    best_mv(F, sh, F.mc_bwd + (size_t) (level - F.p_min) * n, x0, y0, bw, bh, price, bx, by, bbits, bcosts);
+    /* both vectors together: norm of original - (forward block + backward block) / 2, summed in
+     * raster order (mcpe_norm :658-684).  The terms are integers: as long as the total stays
+     * below 2^24 every partial sum is exact and the order does not matter -- summed in parallel;
+     * otherwise lane 0 repeats the sum in order. */
+    const int16_t *orig = F.pix16 + (size_t) y0 * W + x0;
+    const int16_t *r1 = F.past + (size_t) (y0 + fy) * W + (x0 + fx);
+    const int16_t *r2 = F.future + (size_t) (y0 + by) * W + (x0 + bx);
+    unsigned long long part = 0;
+    for (int i = tid; i < bw * bh; i += B) {
+        const int x = i % bw, y = i / bw;
+        const int q = (int) (short) (orig[(size_t) y * W + x] - ((int) r1[(size_t) y * W + x] + (int) r2[(size_t) y * W + x]) / 2) / 16;
+        part += (unsigned long long) (q * q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    __syncthreads();
+    if ((tid & 63) == 0) sh.mcred[tid >> 6] = part;
+    __syncthreads();
     if (tid == 0) {
-        unsigned long long g = sh.mcred[0];
-        for (int i = 1; i < B / 64; i++) if (sh.mcred[i] < g) g = sh.mcred[i];
-        int fx = 0, fy = 0;
-        float costs = MAXCOSTS;
-        if (g != ~0ull && __uint_as_float((unsigned) (g >> 32)) < MAXCOSTS) {
-            const int idx = (int) (g & 0xffffffffu);
-            fx = idx % (2 * sr) - sr; fy = idx / (2 * sr) - sr;
-            costs = __uint_as_float((unsigned) (g >> 32));
+        unsigned long long total = 0;
+        for (int i = 0; i < B / 64; i++) total += sh.mcred[i];
+        float inorm;
+        if (total < (1ull << 24)) inorm = (float) total;
+        else {
+            inorm = 0.0f;
+            for (int y = 0; y < bh; y++)
+                for (int x = 0; x < bw; x++) {
+                    const int q = (int) (short) (orig[(size_t) y * W + x] - ((int) r1[(size_t) y * W + x] + (int) r2[(size_t) y * W + x]) / 2) / 16;
+                    inorm += (float) (q * q);
+                }
         }
-        sh.mc.fx = fx; sh.mc.fy = fy; sh.mc.costs = costs;
-        sh.mc.bits = mv_bits(fx, sr) + mv_bits(fy, sr);
+        const float forward_costs = fcosts + 3 * price, backward_costs = bcosts + 3 * price;
+        const float interp_bits = fbits + bbits;
+        const float interp_costs = inorm + (interp_bits + 2) * price;
+        int type;
+        if (forward_costs <= interp_costs) type = forward_costs <= backward_costs ? MV_FORWARD : MV_BACKWARD;
+        else type = backward_costs <= interp_costs ? MV_BACKWARD : MV_INTERPOLATED;
+        sh.mc.type = type;
+        sh.mc.fx = type != MV_BACKWARD ? fx : 0; sh.mc.fy = type != MV_BACKWARD ? fy : 0;
+        sh.mc.bx = type != MV_FORWARD ? bx : 0; sh.mc.by = type != MV_FORWARD ? by : 0;
+        sh.mc.tree_bits = type == MV_INTERPOLATED ? 2.0f : 3.0f;
+        sh.mc.bits = type == MV_FORWARD ? fbits : type == MV_BACKWARD ? bbits : interp_bits;
     }
 }
 
@@ -1187,17 +1269,21 @@ __device__ void subtract_mc_dev(DevFrame &__restrict__ F, Sh &__restrict__ sh)
     __syncthreads();
     for (int s = F.basis_states; s < sh.states; s++)                 /* blocks do not overlap */
         for (int l = 0; l < 2; l++) {
-            if (F.mv[(0 * 2 + l) * F.PA + s] != MV_FORWARD) continue;       /* uniform */
+            const int type = F.mv[(0 * 2 + l) * F.PA + s];
+            if (type == MV_NONE) continue;       /* uniform */
             const int lv = (int) F.level_of_state[s] - 1;
             const int bw = (int) width_of_level(lv), bh = (int) height_of_level(lv);
             const int x0 = F.x[l * F.PA + s], y0 = F.y[l * F.PA + s];
             const int fx = (F.mv[(1 * 2 + l) * F.PA + s] / 2) * 2, fy = (F.mv[(2 * 2 + l) * F.PA + s] / 2) * 2;
+            const int bx = (F.mv[(3 * 2 + l) * F.PA + s] / 2) * 2, by = (F.mv[(4 * 2 + l) * F.PA + s] / 2) * 2;
             for (int b = 0; b < 2; b++) {
                 int16_t *o = F.pix_chroma + (size_t) b * npix + (size_t) y0 * W + x0;
-                const int16_t *r = F.past + (size_t) (b + 1) * npix + (size_t) (y0 + fy) * W + (x0 + fx);
+                const int16_t *r1 = type == MV_BACKWARD ? F.future + (size_t) (b + 1) * npix + (size_t) (y0 + by) * W + (x0 + bx)
+                                                        : F.past + (size_t) (b + 1) * npix + (size_t) (y0 + fy) * W + (x0 + fx);
+                const int16_t *r2 = type == MV_INTERPOLATED ? F.future + (size_t) (b + 1) * npix + (size_t) (y0 + by) * W + (x0 + bx) : r1;
                 for (int i = tid; i < bw * bh; i += B) {
-                    const int x = i % bw, y = i / bw;
-                    o[(size_t) y * W + x] = (int16_t) (o[(size_t) y * W + x] - r[(size_t) y * W + x]);
+                    const size_t p = (size_t) (i / bw) * W + (i % bw);
+                    o[p] = (int16_t) (o[p] - (type == MV_INTERPOLATED ? ((int) r1[p] + (int) r2[p]) / 2 : (int) r1[p]));
                 }
             }
         }
@@ -1234,9 +1320,11 @@ __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restr
         /* motion compensated prediction error of the range, bintree order, / 16 truncated
          * (get_mcpe + cut_to_bintree, codec/mwfa.c:610-656, codec/subdivide.c:504-541) */
         const Range &rg = fr.rg;
-        const int W = F.width, fx = fr.prange.mv[1], fy = fr.prange.mv[2];
+        const int W = F.width, type = fr.prange.mv[0];
         const int16_t *orig = F.pix16 + (size_t) rg.y * W + rg.x;
-        const int16_t *ref = F.past + (size_t) (rg.y + fy) * W + (rg.x + fx);
+        const int16_t *r1 = type == MV_BACKWARD ? F.future + (size_t) (rg.y + fr.prange.mv[4]) * W + (rg.x + fr.prange.mv[3])
+                                                : F.past + (size_t) (rg.y + fr.prange.mv[2]) * W + (rg.x + fr.prange.mv[1]);
+        const int16_t *r2 = type == MV_INTERPOLATED ? F.future + (size_t) (rg.y + fr.prange.mv[4]) * W + (rg.x + fr.prange.mv[3]) : r1;
         for (int i = tid; i < size; i += B) {
             unsigned xo = 0, yo = 0;
 #pragma unroll
@@ -1244,7 +1332,9 @@ __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restr
                 yo |= ((i >> (2 * b)) & 1u) << b;
                 xo |= ((i >> (2 * b + 1)) & 1u) << b;
             }
-            const short d = (short) (orig[(size_t) yo * W + xo] - ref[(size_t) yo * W + xo]);
+            const size_t o = (size_t) yo * W + xo;
+            const short d = type == MV_INTERPOLATED ? (short) (orig[o] - ((int) r1[o] + (int) r2[o]) / 2)
+                                                    : (short) (orig[o] - r1[o]);
             sh.pixels[i] = (float) ((int) d / 16);
         }
     } else {
@@ -1932,8 +2022,10 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         }
         case PH_PRED_MC2: {                  /* find_P_frame_mc done: vector in sh.mc (prediction.c:282-289) */
             fr.prange = fr.rg;
-            fr.prange.mv[0] = MV_FORWARD; fr.prange.mv[1] = (short) sh.mc.fx; fr.prange.mv[2] = (short) sh.mc.fy;
-            fr.prange.mv_tree_bits = 1; fr.prange.mv_coord_bits = sh.mc.bits;
+            fr.prange.mv[0] = (short) sh.mc.type; fr.prange.mv[1] = (short) sh.mc.fx; fr.prange.mv[2] = (short) sh.mc.fy;
+            fr.prange.mv[3] = (short) sh.mc.bx; fr.prange.mv[4] = (short) sh.mc.by;
+            fr.prange.mv_tree_bits = sh.mc.tree_bits; fr.prange.mv_coord_bits = sh.mc.bits;
+            fr.nd_tbits = sh.mc.tree_bits; fr.nd_wbits = sh.mc.bits;      /* mvt, mvc kept for PH_PRED_DONE */
             fr.pred_costs = (fr.prange.mv_tree_bits + fr.prange.mv_coord_bits) * fr.price;
             fr.phase = PH_PRED_GO;
             break;
@@ -1984,7 +2076,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             Range &rg = fr.rg;
             if (fr.label) {                  /* use the prediction, prediction.c:460-485,152-180 */
                 const int img = rg.image, adr = rg.address;
-                const float mvt = fr.try_pred == 2 ? 1.0f : 0.0f, mvc = fr.try_pred == 2 ? sh.mc.bits : 0.0f;
+                const float mvt = fr.try_pred == 2 ? fr.nd_tbits : 0.0f, mvc = fr.try_pred == 2 ? fr.nd_wbits : 0.0f;
                 rg = fr.prange;
                 rg.image = img; rg.address = adr;
                 if (fr.try_pred == 2) {      /* prediction.c:333-340 */

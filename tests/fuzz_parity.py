@@ -121,7 +121,7 @@ def main():
     # a few multi-frame streams through fiasco_coder() (all-I; colour streams carry the ratcheted
     # minimum block level from frame to frame)
     import tempfile
-    nseq = max(1, rounds // 5)
+    nseq = int(os.environ.get("FUZZ_NSEQ", max(1, rounds // 5)))
     for r in range(nseq):
         rng = np.random.default_rng(seed0 + 100000 + r)
         spec = random_options(rng)
@@ -131,16 +131,22 @@ def main():
         hdr = first.split(b"\n")[1].split()
         w, h = int(hdr[0]), int(hdr[1])
         nfr = int(rng.integers(2, 5))
+        pattern = "i"
+        if os.environ.get("FUZZ_PRED") == "1":          # P and B frames
+            pattern = str(rng.choice(["i", "ip", "ipp", "ippp", "ipip", "ibp", "ibbp", "ipbp", "ipb"]))
         with tempfile.TemporaryDirectory() as td:
             names = []
             for f in range(nfr):
                 a = rng.integers(0, 256, (h, w, 3 if colour else 1)).astype(np.float64)
                 base = np.frombuffer(first[len(first) - w * h * (3 if colour else 1):], np.uint8).reshape(h, w, -1)
+                if pattern != "i":                       # a moving scene: motion compensation can win
+                    base = np.roll(base, (int(rng.integers(-4, 5)) * f, int(rng.integers(-4, 5)) * f), (0, 1))
+                    a = 0.9 * base + 0.1 * a
                 img = np.clip(0.85 * base + 0.15 * a + 3 * f, 0, 255).astype(np.uint8)
                 pth = os.path.join(td, "f%02d.%s" % (f, "ppm" if colour else "pgm"))
                 (synth.write_ppm if colour else synth.write_pgm)(pth, img if colour else img[:, :, 0])
                 names.append(pth)
-            og, oo = gpu.cli_options(pattern="i"), ora.cli_options(pattern="i")
+            og, oo = gpu.cli_options(pattern=pattern), ora.cli_options(pattern=pattern)
             apply(og, spec); apply(oo, spec)
             rg = gpu.fiasco_coder(names, os.path.join(td, "g.fco"), q, og)
             gmsg = gpu.error_message()
@@ -150,8 +156,8 @@ def main():
                 refused += 1
             elif rg != ro or (rg == 1 and open(os.path.join(td, "g.fco"), "rb").read() != open(os.path.join(td, "o.fco"), "rb").read()):
                 bad += 1
-                print("MISMATCH sequence seed %d spec %s q %s colour %s frames %d: rc %d/%d (%s)"
-                      % (seed0 + 100000 + r, spec, q, colour, nfr, rg, ro, gmsg), flush=True)
+                print("MISMATCH sequence seed %d spec %s q %s colour %s frames %d pattern %s: rc %d/%d (%s)"
+                      % (seed0 + 100000 + r, spec, q, colour, nfr, pattern, rg, ro, gmsg), flush=True)
     print("fuzz: %d frames in %d rounds, %d mismatches, %d refused by the device (with message), %.1f s"
           % (n, rounds, bad, refused, time.time() - t0))
     return 1 if bad else 0

@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
     "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload",
-    "fiasco_amd_selftest_log2",
+    "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
+    "fiasco_amd_selftest_log2_max_ulp",
 ]
 
 

@@ -84,14 +84,24 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
  * exponent range and compares the doubles bit for bit with glibc's on the host. */
 #include <math.h>
 #include <pthread.h>
+#include <unistd.h>
 
-__global__ void selftest_log2_kernel(unsigned first_bits, unsigned n, double *out)
+__global__ void selftest_log2_kernel(unsigned first_bits, unsigned n, double *out, const unsigned *keys,
+                                     const double *vals, unsigned mask)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = log2((double) __uint_as_float(first_bits + i));
+    if (i >= n) return;
+    const unsigned k = first_bits + i;
+    double v = log2((double) __uint_as_float(k));
+    if (keys)                                   /* the frame kernel's log2_host(), mp_device.inc */
+        for (unsigned h = (k * 2654435761u) & mask, kk; (kk = keys[h]) != 0; h = (h + 1) & mask)
+            if (kk == k) { v = vals[h]; break; }
+    out[i] = v;
 }
 
-struct L2Task { const double *dev; unsigned first_bits, n, t, nt; unsigned long long dd, df; unsigned bad; };
+struct L2Task { const double *dev; unsigned first_bits, n, t, nt; unsigned long long dd, df; unsigned bad;
+                unsigned long long max_ulp;
+                std::vector<std::pair<unsigned, double>> *collect; };
 
 static void *l2_thread(void *arg)
 {
@@ -101,18 +111,31 @@ static void *l2_thread(void *arg)
         float p; memcpy(&p, &bits, 4);
         double h = log2((double) p), d = k->dev[i];
         if (memcmp(&h, &d, 8) != 0) {
+            long long hb, db;
+            memcpy(&hb, &h, 8); memcpy(&db, &d, 8);
+            unsigned long long dist = (unsigned long long) (hb > db ? hb - db : db - hb);
+            if (dist > k->max_ulp) k->max_ulp = dist;
             k->dd++;
+            if (k->collect) k->collect->push_back(std::make_pair(bits, h));
             if ((float) -h != (float) -d) { if (!k->df) k->bad = bits; k->df++; }
         }
     }
     return nullptr;
 }
 
-/* floats with biased exponent in [exp_lo, exp_hi] (126 = [0.5, 1)); returns 1 when the run
- * completed.  n_double / n_float: arguments whose double result / whose (float) -log2 differ. */
-extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
-                                        unsigned long long *n_double, unsigned long long *n_float,
-                                        float *first_bad)
+/* the table of host log2 values the kernels use (DevFrame.l2_*), per process */
+struct Log2Patch { unsigned *d_keys = nullptr; double *d_vals = nullptr; unsigned mask = 0; int device = -1;
+                   unsigned long long entries = 0; bool tried = false; };
+static Log2Patch g_l2;
+static unsigned long long g_l2_max_ulp;      /* largest distance seen by the last comparisons, in ulps */
+extern "C" unsigned long long fiasco_amd_selftest_log2_max_ulp(void) { return g_l2_max_ulp; }
+
+/* compare over the floats with biased exponent in [exp_lo, exp_hi]; with `use_table` the device
+ * side goes through the patch table like the frame kernel does; `collect` gathers the
+ * arguments that differ together with the host's value */
+static int log2_compare(unsigned exp_lo, unsigned exp_hi, bool use_table, unsigned long long *n_checked,
+                        unsigned long long *n_double, unsigned long long *n_float, float *first_bad,
+                        std::vector<std::pair<unsigned, double>> *collect)
 {
     const unsigned CH = 1u << 23;                  /* one binade per launch */
     double *d_out = nullptr, *h_out = nullptr;
@@ -129,7 +152,8 @@ extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsign
     for (unsigned e = exp_lo; e <= exp_hi; e++) {
         const unsigned first = e << 23;
         const unsigned n = e == 127 ? 1u : CH;     /* 1.0 is the largest probability */
-        hipLaunchKernelGGL(selftest_log2_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, first, n, d_out);
+        hipLaunchKernelGGL(selftest_log2_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, first, n, d_out,
+                           use_table ? g_l2.d_keys : nullptr, use_table ? g_l2.d_vals : nullptr, g_l2.mask);
         if (hipMemcpy(h_out, d_out, (size_t) n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
             fa_set_error("selftest: HIP error: %s", hipGetErrorString(hipGetLastError()));
             (void) hipFree(d_out); (void) hipHostFree(h_out);
@@ -138,17 +162,20 @@ extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsign
         enum { NT = 16 };
         pthread_t th[NT];
         L2Task task[NT];
+        std::vector<std::pair<unsigned, double>> part[NT];
         int started[NT] = { 0 };
         for (unsigned t = 0; t < NT; t++) {
-            task[t] = L2Task{ h_out, first, n, t, NT, 0, 0, 0 };
+            task[t] = L2Task{ h_out, first, n, t, NT, 0, 0, 0, 0, collect ? &part[t] : nullptr };
             if (t) started[t] = pthread_create(&th[t], nullptr, l2_thread, &task[t]) == 0;
         }
         l2_thread(&task[0]);
         for (unsigned t = 1; t < NT; t++) { if (started[t]) pthread_join(th[t], nullptr); else l2_thread(&task[t]); }
         for (unsigned t = 0; t < NT; t++) {
             dd += task[t].dd;
+            if (task[t].max_ulp > g_l2_max_ulp) g_l2_max_ulp = task[t].max_ulp;
             if (task[t].df && !df) bad = task[t].bad;
             df += task[t].df;
+            if (collect) collect->insert(collect->end(), part[t].begin(), part[t].end());
         }
         checked += n;
     }
@@ -158,6 +185,111 @@ extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsign
     if (n_float) *n_float = df;
     if (first_bad) memcpy(first_bad, &bad, 4);
     return 1;
+}
+
+/* floats with biased exponent in [exp_lo, exp_hi] (126 = [0.5, 1)); returns 1 when the run
+ * completed.  n_double / n_float: arguments whose double result / whose (float) -log2 differ. */
+extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
+                                        unsigned long long *n_double, unsigned long long *n_float,
+                                        float *first_bad)
+{
+    return log2_compare(exp_lo, exp_hi, false, n_checked, n_double, n_float, first_bad, nullptr);
+}
+
+static void log2_patch_build(void);
+
+/* the same comparison THROUGH the table the frame kernel uses: n_double must come out 0 */
+extern "C" int fiasco_amd_selftest_log2_patched(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
+                                                unsigned long long *n_double, unsigned long long *n_entries)
+{
+    log2_patch_build();
+    if (n_entries) *n_entries = g_l2.entries;
+    if (!g_l2.d_keys && g_l2.entries) { fa_set_error("selftest: no log2 table on this device"); return 0; }
+    return log2_compare(exp_lo, exp_hi, g_l2.d_keys != nullptr, n_checked, n_double, nullptr, nullptr, nullptr);
+}
+
+/* Build (or load from the cache file) the table of this process: every float in (0, 1] whose
+ * device log2 differs from the host's, with the host's value.  About a second of work the first
+ * time on a box; the list (some 12 MB) is then kept in $FIASCO_AMD_CACHE (default /tmp) under a
+ * name that carries the host libm's and the device's answers to a few probe arguments, and is
+ * re-validated on load. */
+static void log2_patch_build(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (g_l2.tried && g_l2.device == dev) return;
+    if (g_l2.d_keys) { (void) hipFree(g_l2.d_keys); (void) hipFree(g_l2.d_vals); g_l2 = Log2Patch(); }
+    g_l2.tried = true; g_l2.device = dev;
+    if (getenv("FIASCO_AMD_NO_LOG2_TABLE")) return;
+    std::vector<std::pair<unsigned, double>> list;
+    char path[512];
+    {
+        /* fingerprint: host libm on a few awkward arguments + device name */
+        hipDeviceProp_t prop;
+        unsigned long long fp = 1469598103934665603ull;
+        const float probe[] = { 0.3f, 1.0f / 3, 0.7f, 5.0f / 7, 0.0123f, 0.999f, 1e-3f, 0.57f };
+        for (unsigned i = 0; i < sizeof probe / sizeof probe[0]; i++) {
+            double v = log2((double) probe[i]);
+            unsigned long long b; memcpy(&b, &v, 8);
+            fp = (fp ^ b) * 1099511628211ull;
+        }
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            for (const char *c = prop.gcnArchName; *c; c++) fp = (fp ^ (unsigned char) *c) * 1099511628211ull;
+        int rt = 0; (void) hipRuntimeGetVersion(&rt);
+        fp = (fp ^ (unsigned) rt) * 1099511628211ull;
+        const char *dir = getenv("FIASCO_AMD_CACHE");
+        snprintf(path, sizeof path, "%s/fiasco_amd_log2_%016llx.bin", dir && *dir ? dir : "/tmp", fp);
+    }
+    bool loaded = false;
+    if (FILE *f = fopen(path, "rb")) {
+        unsigned long long hdr[2] = { 0, 0 };
+        if (fread(hdr, 8, 2, f) == 2 && hdr[0] == 0x32474f4c41464full && hdr[1] < (1ull << 26)) {
+            list.resize((size_t) hdr[1]);
+            loaded = fread(list.data(), sizeof list[0], list.size(), f) == list.size();
+            /* the stored values must still be what this host computes */
+            for (size_t i = 0; loaded && i < list.size(); i += 1 + list.size() / 4096) {
+                float p; memcpy(&p, &list[i].first, 4);
+                double v = log2((double) p);
+                if (memcmp(&v, &list[i].second, 8) != 0) loaded = false;
+            }
+        }
+        fclose(f);
+        if (!loaded) list.clear();
+    }
+    if (!loaded) {
+        unsigned long long nd = 0;
+        if (!log2_compare(1, 127, false, nullptr, &nd, nullptr, nullptr, &list)) { list.clear(); return; }
+        char tmp[560];
+        snprintf(tmp, sizeof tmp, "%s.%d", path, (int) getpid());
+        if (FILE *f = fopen(tmp, "wb")) {
+            unsigned long long hdr[2] = { 0x32474f4c41464full, (unsigned long long) list.size() };
+            bool ok = fwrite(hdr, 8, 2, f) == 2 && fwrite(list.data(), sizeof list[0], list.size(), f) == list.size();
+            fclose(f);
+            if (!ok || rename(tmp, path) != 0) (void) remove(tmp);
+        }
+    }
+    g_l2.entries = list.size();
+    if (list.empty()) return;
+    unsigned slots = 1024;
+    while (slots < 4 * list.size()) slots <<= 1;
+    std::vector<unsigned> keys(slots, 0u);
+    std::vector<double> vals(slots, 0.0);
+    for (size_t i = 0; i < list.size(); i++) {
+        unsigned h = (list[i].first * 2654435761u) & (slots - 1);
+        while (keys[h]) h = (h + 1) & (slots - 1);
+        keys[h] = list[i].first; vals[h] = list[i].second;
+    }
+    if (hipMalloc((void **) &g_l2.d_keys, (size_t) slots * 4) != hipSuccess
+        || hipMalloc((void **) &g_l2.d_vals, (size_t) slots * 8) != hipSuccess
+        || hipMemcpy(g_l2.d_keys, keys.data(), (size_t) slots * 4, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(g_l2.d_vals, vals.data(), (size_t) slots * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        (void) hipGetLastError();
+        if (g_l2.d_keys) (void) hipFree(g_l2.d_keys);
+        if (g_l2.d_vals) (void) hipFree(g_l2.d_vals);
+        g_l2.d_keys = nullptr; g_l2.d_vals = nullptr;
+        return;
+    }
+    g_l2.mask = slots - 1;
 }
 
 /* ------------------------------------------------------------------ slab pool */
@@ -439,6 +571,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pos = (int16_t *) (base + L.pos);
     F.hits = (int *) (base + L.hits);
     F.snap_hbm = fs.big ? (void *) (base + L.snap) : nullptr;
+    F.l2_keys = g_l2.d_keys; F.l2_vals = g_l2.d_vals; F.l2_mask = g_l2.mask;
     /* prediction (codec/coder.c:716-745): gray frames try it from the root; a colour frame only
      * gets the second rle pool (intra prediction is never asked for its bands, :805-806) */
     const int inter = job->frame_type != FA_I_FRAME;
@@ -578,6 +711,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                      "libfiasco_amd: no HIP device available (the hot path has no CPU fallback)");
         return S;
     }
+    log2_patch_build();                      /* once per process and device */
     if (hipStreamCreate(&S->stream) != hipSuccess || hipEventCreate(&S->ev0) != hipSuccess
         || hipEventCreate(&S->ev1) != hipSuccess
         || hipMalloc((void **) &S->d_frames, sizeof(DevFrame) * (n ? n : 1)) != hipSuccess) {

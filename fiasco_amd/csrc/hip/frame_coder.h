@@ -109,6 +109,12 @@ typedef struct DevFrame {
     const void *pack_src;
     void    *pack_dst;
     unsigned pack_bytes;
+    /* ---- log2 of a float probability exactly as the HOST's libm gives it (core_hip.cpp) ----
+     * open-addressing table of the arguments for which the device's log2 differs: key = bits of
+     * the float (0 = empty slot), value = the host's double; null = no table */
+    const unsigned *l2_keys;
+    const double   *l2_vals;
+    unsigned        l2_mask;
     /* ---- results ---- */
     int      status;
     int      states, root_state;

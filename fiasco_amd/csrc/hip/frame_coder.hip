@@ -269,6 +269,7 @@ struct Sh {
         /* the same for the matching pursuit: table bases and quantiser parameters */
         float *gram, *diag, *ipis; int16_t *pos;
         float *d5, *d4;            /* big build: the active level-5 / level-4 dot tables */
+        const unsigned *l2_keys; const double *l2_vals; unsigned l2_mask;
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
         float rpf_range, dc_range;
     } par;
@@ -2286,6 +2287,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
         sh.par.gram = F.gram; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
         sh.par.d5 = F.d5; sh.par.d4 = F.d4;
+        sh.par.l2_keys = F.l2_keys; sh.par.l2_vals = F.l2_vals; sh.par.l2_mask = F.l2_mask;
         sh.par.max_elements = F.max_elements; sh.par.rpf_mant = F.rpf_mant; sh.par.dc_mant = F.dc_mant;
         sh.par.sy = F.sy; sh.par.dcs = F.dcs; sh.par.gl0 = F.gl0; sh.par.images_level = F.images_level;
         sh.par.lc_min_opt = F.lc_min; sh.par.trace_on = F.trace != nullptr;

@@ -58,6 +58,16 @@ int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsigned long lon
                              unsigned long long *n_double, unsigned long long *n_float,
                              float *first_bad);
 
+/* The same comparison through the table the frame kernel consults for the arguments on which the
+ * two libm's differ (built once per process and device, cached under $FIASCO_AMD_CACHE or
+ * /tmp): n_double must be 0 -- the coefficient prices, which subtract these doubles from a float
+ * sum (codec/coeff.c:228-236), are then the host's for every probability that can occur.
+ * n_entries = size of the table. */
+/* largest distance, in ulps, between a device and a host logarithm seen by the comparisons so far */
+unsigned long long fiasco_amd_selftest_log2_max_ulp(void);
+int fiasco_amd_selftest_log2_patched(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
+                                     unsigned long long *n_double, unsigned long long *n_entries);
+
 #ifdef __cplusplus
 }
 #endif

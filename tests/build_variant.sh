@@ -1,0 +1,16 @@
+#!/bin/bash
+# developer helper: build fiasco_amd/libfiasco_amd_<name>.so with extra flags for the frame kernels
+# usage: tests/build_variant.sh name "-DFC_SERIAL_PROFILE=1 ..."   (test with FIASCO_AMD_LIB=...)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; extra=${2:-}
+cd $R/fiasco_amd/csrc
+make -s >/dev/null
+B=build/var_$name; mkdir -p $B
+HF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -Ihost -Ihip"
+/opt/rocm/bin/hipcc $HF $extra -c hip/frame_coder.hip -o $B/frame_coder.o &
+/opt/rocm/bin/hipcc $HF $extra -DFC_VARIANT_WIDE=1 -c hip/frame_coder.hip -o $B/frame_coder_wide.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfiasco_amd_$name.so build/fa_*.o $B/frame_coder.o $B/frame_coder_wide.o \
+   build/frame_coder_big.o build/frame_coder_big_wide.o build/core_hip.o -lm -lpthread
+echo built fiasco_amd/libfiasco_amd_$name.so

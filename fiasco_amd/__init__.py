@@ -40,6 +40,9 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
+    "fiasco_amd_seq_open", "fiasco_amd_seq_free", "fiasco_amd_seq_gops", "fiasco_amd_seq_frames",
+    "fiasco_amd_seq_gop_of", "fiasco_amd_seq_ycol_size", "fiasco_amd_seq_initial_level",
+    "fiasco_amd_seq_search", "fiasco_amd_seq_gop_result", "fiasco_amd_seq_ycol", "fiasco_amd_seq_write",
 ]
 
 
@@ -281,6 +284,80 @@ class Batch:
     def free(self):
         if self.handle:
             self.lib.L.fiasco_amd_batch_free(self.handle)
+            self.handle = None
+
+
+class Sequence:
+    """fiasco_amd_seq_*: one video, this process searching and writing every world-th group of
+    pictures (include/libfiasco_amd.h).  Frames: raw PNM bytes in display order."""
+
+    def __init__(self, lib, pnm_list, quality=20.0, options=None, rank=0, world=1):
+        c = ctypes
+        L = self.L = lib.L
+        self.lib = lib
+        L.fiasco_amd_seq_open.argtypes = [c.c_uint, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t), c.c_float,
+                                          c.c_void_p, c.c_uint, c.c_uint]
+        L.fiasco_amd_seq_open.restype = c.c_void_p
+        L.fiasco_amd_seq_free.argtypes = [c.c_void_p]
+        for name in ("gops", "frames", "ycol_size", "initial_level"):
+            f = getattr(L, "fiasco_amd_seq_" + name)
+            f.argtypes = [c.c_void_p]; f.restype = c.c_uint
+        L.fiasco_amd_seq_gop_of.argtypes = [c.c_void_p, c.c_uint]; L.fiasco_amd_seq_gop_of.restype = c.c_uint
+        L.fiasco_amd_seq_search.argtypes = [c.c_void_p, c.POINTER(c.c_uint), c.POINTER(c.c_ubyte)]
+        L.fiasco_amd_seq_search.restype = c.c_int
+        L.fiasco_amd_seq_gop_result.argtypes = [c.c_void_p, c.c_uint, c.POINTER(c.c_uint), c.POINTER(c.c_int)]
+        L.fiasco_amd_seq_gop_result.restype = c.c_int
+        L.fiasco_amd_seq_ycol.argtypes = [c.c_void_p, c.c_uint]; L.fiasco_amd_seq_ycol.restype = c.c_void_p
+        L.fiasco_amd_seq_write.argtypes = [c.c_void_p, c.c_uint, c.c_char_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]
+        L.fiasco_amd_seq_write.restype = c.c_int
+        self._keep = (list(pnm_list), options)                      # borrowed by the C side
+        n = len(pnm_list)
+        self._bufs = (c.c_char_p * n)(*pnm_list)
+        self._lens = (c.c_size_t * n)(*[len(b) for b in pnm_list])
+        self.handle = L.fiasco_amd_seq_open(n, self._bufs, self._lens, c.c_float(quality),
+                                            options.handle if options else None, rank, world)
+        if not self.handle:
+            raise FiascoError(lib.error_message())
+        self.rank, self.world = rank, world
+        self.gops = L.fiasco_amd_seq_gops(self.handle)
+        self.frames = L.fiasco_amd_seq_frames(self.handle)
+        self.ycol_size = L.fiasco_amd_seq_ycol_size(self.handle)
+        self.initial_level = L.fiasco_amd_seq_initial_level(self.handle)
+
+    def gop_of(self, frame):
+        return self.L.fiasco_amd_seq_gop_of(self.handle, frame)
+
+    def search(self, carry_in, todo):
+        c = ctypes
+        ci = (c.c_uint * self.gops)(*carry_in)
+        td = (c.c_ubyte * self.gops)(*[1 if t else 0 for t in todo])
+        if not self.L.fiasco_amd_seq_search(self.handle, ci, td):
+            raise FiascoError(self.lib.error_message())
+
+    def gop_result(self, gop):
+        """(minimum level the GOP left, failed, message) -- None if the GOP was not searched here."""
+        c = ctypes
+        out, failed = c.c_uint(), c.c_int()
+        if not self.L.fiasco_amd_seq_gop_result(self.handle, gop, out, failed):
+            return None
+        return out.value, bool(failed.value), self.lib.error_message() if failed.value else ""
+
+    def ycol(self, frame):
+        p = self.L.fiasco_amd_seq_ycol(self.handle, frame)
+        return ctypes.string_at(p, self.ycol_size) if p and self.ycol_size else None
+
+    def write(self, frame, ycol=None):
+        c = ctypes
+        out, n = c.c_void_p(), c.c_size_t()
+        if not self.L.fiasco_amd_seq_write(self.handle, frame, ycol, out, n):
+            raise FiascoError(self.lib.error_message())
+        data = c.string_at(out, n.value)
+        self.L.fiasco_amd_free(out)
+        return data
+
+    def free(self):
+        if self.handle:
+            self.L.fiasco_amd_seq_free(self.handle)
             self.handle = None
 
 

@@ -192,54 +192,6 @@ bad:
     return NULL;
 }
 
-/* pattern2type, codec/coder.c:670-690; the first frame is always intra (:522-523) */
-static int frame_type_of(unsigned display, const char *pattern, int *ok)
-{
-    int c = toupper((unsigned char) pattern[display % strlen(pattern)]);
-    *ok = 1;
-    if (display == 0 || c == 'I') return FA_I_FRAME;
-    if (c == 'P') return FA_P_FRAME;
-    if (c == 'B') return FA_B_FRAME;
-    fa_set_error("Frame type %c not valid. Choose one of I,B or P.", c);
-    *ok = 0;
-    return FA_I_FRAME;
-}
-
-/* The order in which video_coder (codec/coder.c:490-668) codes the frames of a sequence and
- * the type it gives each: a run of B frames is preceded by its future reference, which is the
- * next non-B frame of the pattern or -- at the end of the sequence -- the last frame, coded as
- * a P frame.  order[k] = display number of the k-th coded frame.  Returns 0 on a pattern error. */
-static int coding_order(unsigned nframes, const char *pattern, unsigned *order, int *type, int *is_future)
-{
-    unsigned display = 0, k = 0;
-    int future_display = -1, ok;
-    while (display < nframes) {
-        int t = frame_type_of(display, pattern, &ok);
-        unsigned frame;
-        if (!ok) return 0;
-        if ((int) display == future_display) { display++; continue; }
-        if (t == FA_B_FRAME && (int) display > future_display) {
-            unsigned i = display;
-            while (t == FA_B_FRAME) {
-                i++;
-                if (i >= nframes) { future_display = (int) i - 1; t = FA_P_FRAME; }
-                else {
-                    future_display = (int) i;
-                    t = frame_type_of(i, pattern, &ok);
-                    if (!ok) return 0;
-                }
-            }
-            frame = (unsigned) future_display;
-        } else {
-            frame = display;
-            display++;
-        }
-        order[k] = frame; type[k] = t; is_future[k] = (int) frame == future_display;
-        k++;
-    }
-    return (int) k;
-}
-
 /* ---------------------------------------------------------------- one still -> bytes */
 
 static int prepare_job(fa_job *job, const fa_image *im, const fa_cparams *cp, const char *basis)
@@ -257,14 +209,14 @@ static int prepare_job(fa_job *job, const fa_image *im, const fa_cparams *cp, co
     return 1;
 }
 
-static void report(const fa_job *job, const fa_info *wi)
+static void report(const fa_wfa *wfa, const fa_stats *stats, const fa_info *wi)
 {
     int b, nb = wi->color ? 3 : 1;
     for (b = 0; b < nb; b++) {
-        const fa_stats *s = &job->stats[b];
+        const fa_stats *s = &stats[b];
         double mse = s->err / wi->width / wi->height;
-        fa_debug("WFA contains %d states (%d basis states).", (int) job->wfa->states,
-                 (int) job->wfa->basis_states);
+        fa_debug("WFA contains %d states (%d basis states).", (int) wfa->states,
+                 (int) wfa->basis_states);
         fa_debug("Estimated error: %.2f (RMSE: %.2f, PSNR: %.2f dB).", (double) s->err,
                  sqrt(mse), 10 * log(255.0 * 255.0 / mse) / log(10.0));
         fa_debug("(T: %.0f, M: %.0f, W: %.0f)", (double) s->tree_bits, (double) s->matrix_bits,
@@ -282,21 +234,15 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     char const *const *templ;
     fiasco_c_options_t *defaults = NULL;
     const fa_options *op;
-    fa_info wi;
-    fa_cparams cp;
     fa_bitw out;
     FILE *fout = NULL;
-    unsigned nframes = 0, i, w = 0, h = 0;
-    int color = 0, rc = 0, have_out = 0, err;
+    unsigned nframes = 0, i;
+    int rc = 0, have_out = 0, err;
     char **names = NULL;
     unsigned char **bufs = NULL;
     size_t *lens = NULL;
-    unsigned carry_min_level;
-    uint8_t *carry_ycol = NULL;
-    unsigned *order = NULL;
-    int *types = NULL, *isfut = NULL, ncoded = 0, video = 0, last_was_future = 0;
+    fa_seq *seq = NULL;
 
-    memset(&wi, 0, sizeof wi);
     templ = (!inputname || !inputname[0] || strcmp(inputname[0], "-") == 0) ? default_input : inputname;
     if (quality <= 0) { fa_set_error("Compression quality has to be positive."); return 0; }
     if (quality >= 100)
@@ -310,15 +256,7 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
         op = fa_cast_options(defaults);
     }
 
-    /* output stream is opened (and truncated) before anything else can fail */
-    fout = open_file(outputname, "FIASCO_DATA", WRITE_ACCESS);
-    if (!fout) {
-        fa_set_error("Can't write outputfile `%s'.\n%s", outputname ? outputname : "<stdout>",
-                     strerror(errno));
-        goto done;
-    }
-
-    /* enumerate frames; all must agree in size and colour model */
+    /* the frame names (no file is touched yet) */
     for (;; nframes++) {
         char *nm = input_name(templ, nframes, &err);
         if (!nm) { if (err) goto done; break; }
@@ -333,126 +271,36 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
         }
         names[nframes] = nm; bufs[nframes] = NULL; lens[nframes] = 0;
     }
+    /* what this library refuses is refused before the output file is truncated */
+    if (nframes > 1 && op->half_pixel_prediction) {
+        fa_set_error("Half-pixel motion vectors are not supported (the reference coder's half-pixel "
+                     "path reads outside the reference frame).");
+        goto done;
+    }
+
+    /* the reference opens (and truncates) the output stream before anything else can fail */
+    fout = open_file(outputname, "FIASCO_DATA", WRITE_ACCESS);
+    if (!fout) {
+        fa_set_error("Can't write outputfile `%s'.\n%s", outputname ? outputname : "<stdout>",
+                     strerror(errno));
+        goto done;
+    }
     for (i = 0; i < nframes; i++) {
-        unsigned fw, fh; int fc; size_t off;
         const char *nm = strcmp(names[i], "-") == 0 ? NULL : names[i];
         bufs[i] = fa_read_whole_file(nm, "FIASCO_IMAGES", &lens[i]);
         if (!bufs[i]) {
             fa_set_error("Can't open frame `%s'.\n%s", names[i], strerror(errno));
             goto done;
         }
-        if (!fa_pnm_header(bufs[i], lens[i], names[i], &fw, &fh, &fc, &off)) goto done;
-        if (i == 0) { w = fw; h = fh; color = fc; }
-        else if (fw != w || fh != h) {
-            fa_set_error("`%s': all images of a sequence have to be of the same size.", names[i]);
-            goto done;
-        } else if (fc != color) {
-            fa_set_error("`%s': all images a sequence have to use the same color model.", names[i]);
-            goto done;
-        }
     }
     if (nframes == 0) { fa_set_error("Can't open frame `%s'.", "<none>"); goto done; }
 
-    if (!fa_setup_params(op, quality, w, h, color, nframes, &wi, &cp)) goto done;
-    order = (unsigned *) calloc(nframes, sizeof *order);
-    types = (int *) calloc(nframes, sizeof *types);
-    isfut = (int *) calloc(nframes, sizeof *isfut);
-    if (!order || !types || !isfut) { fa_set_error("Out of memory!"); goto done; }
-    ncoded = coding_order(nframes, op->pattern, order, types, isfut);
-    if (ncoded <= 0) goto done;
-    for (i = 0; i < (unsigned) ncoded; i++) if (types[i] != FA_I_FRAME) video = 1;
-
+    /* video_coder (codec/coder.c:490-668): the groups of pictures side by side, fa_sequence.c */
+    seq = fa_seq_open(op, quality, nframes, (const unsigned char *const *) bufs, lens,
+                      (char const *const *) names, 0, 1);
+    if (!seq) goto done;
     fa_bw_init(&out); have_out = 1;
-    carry_min_level = cp.lc_min_level;
-    carry_ycol = NULL;
-    if (!video && !color) {
-        /* Gray all-intra frames are independent and go to the core as one batch. */
-        fa_job *jobs = (fa_job *) calloc(nframes, sizeof *jobs);
-        fa_image **ims = (fa_image **) calloc(nframes, sizeof *ims);
-        unsigned k, good;
-        int failed = !jobs || !ims;
-        if (failed) fa_set_error("Out of memory!");
-        for (k = 0; k < nframes && !failed; k++) {
-            ims[k] = fa_image_from_pnm(bufs[k], lens[k], names[k]);
-            if (!ims[k] || !prepare_job(&jobs[k], ims[k], &cp, op->basis_name)) failed = 1;
-        }
-        if (!failed) {
-            good = (unsigned) fa_core_encode_frames(nframes, jobs);
-            if (good != nframes) {
-                for (k = 0; k < nframes; k++)
-                    if (!jobs[k].status) { fa_set_error("%s", jobs[k].errmsg); break; }
-                failed = 1;
-            }
-        }
-        for (k = 0; k < nframes && !failed; k++) {
-            report(&jobs[k], &wi);
-            if (!fa_write_frame(jobs[k].wfa, &wi, FA_I_FRAME, k, op->prediction, op->normal_domains,
-                                op->delta_domains, &out))
-                failed = 1;
-        }
-        for (k = 0; jobs && ims && k < nframes; k++) { fa_wfa_free(jobs[k].wfa); fa_image_free(ims[k]); }
-        free(jobs); free(ims);
-        if (failed) goto done;
-    } else {
-        /* video_coder (codec/coder.c:490-668): the frames one after the other in coding order.
-         * Colour frames carry lc_min_level from frame to frame (:785-797); a P/B frame is
-         * predicted from the RECONSTRUCTED frames before it (:580-651). */
-        fa_image *reconst = NULL, *past = NULL, *future = NULL;
-        int failed = 0;
-        for (i = 0; i < (unsigned) ncoded && !failed; i++) {
-            const unsigned frame = order[i];
-            const int type = types[i];
-            fa_job job;
-            fa_image *im;
-            if (type == FA_I_FRAME) {
-                fa_image_free(past); fa_image_free(future); fa_image_free(reconst);
-                past = future = reconst = NULL;
-            } else if (type == FA_P_FRAME) {
-                fa_image_free(past); past = reconst; reconst = NULL;
-                fa_image_free(future); future = NULL;
-            } else if (last_was_future) {
-                fa_image_free(future); future = reconst; reconst = NULL;
-            } else if (wi.B_as_past_ref) {
-                fa_image_free(past); past = reconst; reconst = NULL;
-            } else {
-                fa_image_free(reconst); reconst = NULL;
-            }
-            last_was_future = isfut[i];
-            im = fa_image_from_pnm(bufs[frame], lens[frame], names[frame]);
-            if (!im) { failed = 1; break; }
-            cp.lc_min_level = carry_min_level;
-            if (!prepare_job(&job, im, &cp, op->basis_name)) { fa_wfa_free(job.wfa); fa_image_free(im); failed = 1; break; }
-            job.frame_type = type; job.past = past; job.future = future;
-            if (color && carry_ycol) {
-                /* the y_column flags the previous frame left behind (see fa_job.ycol_carry) */
-                memcpy(job.wfa->y_column, carry_ycol, (size_t) job.wfa->cap * 2);
-                job.ycol_carry = 1;
-            }
-            if (fa_core_encode_frames(1, &job) != 1) { fa_set_error("%s", job.errmsg); failed = 1; }
-            if (!failed) {
-                report(&job, &wi);
-                if (!fa_write_frame(job.wfa, &wi, type, frame, op->prediction, op->normal_domains,
-                                    op->delta_domains, &out))
-                    failed = 1;
-            }
-            if (!failed) {
-                carry_min_level = job.lc_min_level_out;
-                if (color) {
-                    if (!carry_ycol) carry_ycol = (uint8_t *) malloc((size_t) job.wfa->cap * 2);
-                    if (carry_ycol) memcpy(carry_ycol, job.wfa->y_column, (size_t) job.wfa->cap * 2);
-                }
-                if (video && i + 1 < (unsigned) ncoded) {      /* reference for the frames to come */
-                    reconst = fa_decode_image(wi.width, wi.height, job.wfa, color);
-                    if (!reconst || (type != FA_I_FRAME
-                                     && !fa_restore_mc(reconst, past, future, job.wfa, wi.p_max_level)))
-                        failed = 1;
-                }
-            }
-            fa_wfa_free(job.wfa); fa_image_free(im);
-        }
-        fa_image_free(reconst); fa_image_free(past); fa_image_free(future);
-        if (failed || i < (unsigned) ncoded) goto done;
-    }
+    if (!fa_seq_encode_all(seq, &out, report)) goto done;
     {
         size_t nbytes = fa_bw_finish(&out);
         if (fwrite(out.buf, 1, nbytes, fout) != nbytes) {
@@ -462,14 +310,12 @@ int fiasco_coder(char const *const *inputname, const char *outputname, float qua
     }
     rc = 1;
 done:
-    free(order); free(types); free(isfut);
-    free(carry_ycol);
+    fa_seq_free(seq);
     if (have_out) fa_bw_free(&out);
     if (fout && fout != stdout) fclose(fout);
     else if (fout) fflush(fout);
     for (i = 0; i < nframes; i++) { free(names[i]); free(bufs ? bufs[i] : NULL); }
     free(names); free(bufs); free(lens);
-    fa_info_free(&wi);
     if (defaults) fiasco_c_options_delete(defaults);
     return rc;
 }

@@ -254,6 +254,28 @@ int  fa_write_frame(const fa_wfa *wfa, const fa_info *wi, int frame_type, unsign
 /* stable (count desc, state asc) top-n hits, reference codec/wfalib.c:182-231 */
 int16_t *fa_compute_hits(unsigned from, unsigned to, unsigned n, const fa_wfa *wfa);
 
+/* ---------------- sequences: frames in coding order, GOPs side by side (fa_sequence.c) ----- */
+typedef struct fa_seq fa_seq;
+fa_seq *fa_seq_open(const fa_options *op, float quality, unsigned nframes, const unsigned char *const *bufs,
+                    const size_t *lens, char const *const *names, unsigned rank, unsigned world);
+void    fa_seq_free(fa_seq *s);
+int     fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo);
+int     fa_seq_encode_all(fa_seq *s, fa_bitw *out,
+                          void (*report)(const fa_wfa *, const fa_stats *, const fa_info *));
+unsigned fa_seq_gops(const fa_seq *s);
+unsigned fa_seq_frames(const fa_seq *s);
+unsigned fa_seq_ycol_size(const fa_seq *s);
+unsigned fa_seq_initial_level(const fa_seq *s);
+unsigned fa_seq_gop_of(const fa_seq *s, unsigned k);
+int      fa_seq_is_mine(const fa_seq *s, unsigned gop);
+void     fa_seq_gop_result(const fa_seq *s, unsigned gop, unsigned *carry_out, int *failed);
+const char *fa_seq_gop_error(const fa_seq *s, unsigned gop);
+const fa_stats *fa_seq_stats(const fa_seq *s, unsigned k);
+const fa_info *fa_seq_info(const fa_seq *s);
+const uint8_t *fa_seq_ycol_raw(const fa_seq *s, unsigned k);
+void     fa_seq_ycol_resolve(uint8_t *chain, const uint8_t *raw, unsigned n);
+int      fa_seq_write(fa_seq *s, unsigned k, const uint8_t *ycol, fa_bitw *out);
+
 /* ---------------- frame driver pieces shared by fiasco_coder and the batch API ----- */
 unsigned fa_image_level(unsigned width, unsigned height);      /* codec/coder.c:247-255 */
 int fa_setup_params(const fa_options *op, float quality, unsigned width, unsigned height,

@@ -1,4 +1,4 @@
-"""Frame sharding across the GPUs of one node (one process per GPU).
+"""Frame and GOP sharding across the GPUs of one node (one process per GPU).
 
 The hot path shards over independent frames: separate ``fiasco_coder``
 calls / grayscale all-intra frames share no state, so rank r simply encodes frames
@@ -42,3 +42,86 @@ def gather_streams(local, n_items, device="cpu", group=None):
         for k, i in enumerate(shard_indices(n_items, r, world)):
             out[i] = bytes(p[k, :lens[i]].numpy().tobytes())
     return out
+
+
+def encode_sequence(lib, pnm_list, quality=20.0, options=None, device="cpu", group=None):
+    """One video over all ranks: rank r searches and writes the groups of pictures r, r+W, ...
+    (independent but for two things a colour stream carries from frame to frame):
+
+      * the minimum block level (reference codec/coder.c:785-797) -- every GOP starts from a
+        SPECULATED level; one all-reduce gathers what each GOP left; the chain is verified on
+        every rank alike and the GOPs behind the first wrong start value are searched again;
+      * the y_column flags (codec/wfalib.c:277-310) -- one all-reduce gathers the raw flags of
+        all frames, every rank resolves them in coding order and writes its own frames.
+
+    The byte strings of the frames are then gathered like independent frames (gather_streams) and
+    put together in coding order.  Returns the .fco bytes on every rank."""
+    import fiasco_amd
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    seq = fiasco_amd.Sequence(lib, pnm_list, quality, options, rank, world)
+    try:
+        G, K = seq.gops, seq.frames
+        carry = [seq.initial_level] * G
+        todo = [True] * G
+        used, left, failed = [0] * G, [0] * G, [False] * G
+        for _ in range(64):
+            seq.search(carry, todo)
+            mine = torch.zeros((G, 3), dtype=torch.int64, device=device)
+            for g in range(G):
+                if g % world == rank and todo[g]:
+                    out, bad, _msg = seq.gop_result(g)
+                    mine[g] = torch.tensor([carry[g], out, 1 if bad else 0], dtype=torch.int64, device=device)
+            if world > 1:
+                dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=group)
+            got = mine.cpu().tolist()
+            for g in range(G):
+                if todo[g]:
+                    used[g], left[g], failed[g] = got[g][0], got[g][1], bool(got[g][2])
+            t, first_invalid = seq.initial_level, G
+            for g in range(G):
+                if used[g] != t:
+                    first_invalid = g
+                    break
+                if failed[g]:
+                    raise fiasco_amd.FiascoError("group of pictures %d: the coder failed" % g)
+                t = left[g]
+            if first_invalid == G:
+                break
+            todo = [g >= first_invalid for g in range(G)]
+            carry = [t if todo[g] else carry[g] for g in range(G)]
+        else:
+            raise fiasco_amd.FiascoError("minimum level chain does not settle")
+        # y_column chain (colour only): raw flags of every frame -> resolved flags of my frames
+        resolved = {}
+        if seq.ycol_size:
+            raw = torch.zeros((K, seq.ycol_size), dtype=torch.uint8, device=device)
+            for k in range(K):
+                if seq.gop_of(k) % world == rank:
+                    raw[k] = torch.frombuffer(bytearray(seq.ycol(k)), dtype=torch.uint8).to(device)
+            if world > 1:
+                dist.all_reduce(raw, op=dist.ReduceOp.SUM, group=group)
+            raw = raw.cpu()
+            chain = torch.zeros(seq.ycol_size, dtype=torch.uint8)
+            for k in range(K):
+                chain = torch.where(raw[k] != 2, raw[k], chain)
+                if seq.gop_of(k) % world == rank:
+                    resolved[k] = bytes(chain.numpy().tobytes())
+        local = {k: seq.write(k, resolved.get(k)) for k in range(K) if seq.gop_of(k) % world == rank}
+    finally:
+        seq.free()
+    if world == 1:
+        return b"".join(local[k] for k in range(K))
+    # gather_streams expects item i on rank i % world: the frames are owned by GOP, so gather in
+    # two steps -- lengths, then the payloads padded to the longest
+    lengths = torch.zeros(K, dtype=torch.int64, device=device)
+    for k, b in local.items():
+        lengths[k] = len(b)
+    dist.all_reduce(lengths, op=dist.ReduceOp.SUM, group=group)
+    lens = lengths.cpu().tolist()
+    buf = torch.zeros((K, max(lens) if K else 1), dtype=torch.uint8, device=device)
+    for k, b in local.items():
+        buf[k, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = buf.cpu()
+    return b"".join(bytes(buf[k, :lens[k]].numpy().tobytes()) for k in range(K))

@@ -155,6 +155,36 @@ int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigne
                             float *costs, float *err, unsigned *width, unsigned *height);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
 
+/* ---- sequences across processes (one process per GPU) ---------------------------------------
+ * fiasco_coder() codes a video by searching its groups of pictures (an I frame and what follows
+ * up to the next I frame; reference codec/coder.c:581-592) side by side on one GPU.  With these
+ * entries process `rank` of `world` searches and writes every world-th GOP of the same sequence;
+ * what the processes exchange is left to the caller (fiasco_amd/sharding.py: torch.distributed):
+ *   - colour streams hand the minimum block level from frame to frame (codec/coder.c:785-797):
+ *     search with a speculated level per GOP (carry_in), gather what every GOP left
+ *     (gop_result), search again from the first GOP whose start value was wrong;
+ *   - the y_column flags that show through from frame to frame (codec/wfalib.c:277-310): gather
+ *     the raw flags of every frame (seq_ycol: 2 = "not written by this frame"), resolve them in
+ *     coding order, hand the resolved flags of a frame to seq_write;
+ *   - the byte strings of the frames in coding order are the stream.
+ * Frames are given as raw PNM buffers in DISPLAY order; they and `options` must stay alive until
+ * seq_free.  All functions return 1 / non-NULL on success, 0 / NULL + message otherwise. */
+typedef struct fiasco_amd_seq fiasco_amd_seq_t;
+fiasco_amd_seq_t *fiasco_amd_seq_open(unsigned n, const unsigned char *const *pnm, const size_t *pnm_len,
+                                      float quality, const fiasco_c_options_t *options,
+                                      unsigned rank, unsigned world);
+void     fiasco_amd_seq_free(fiasco_amd_seq_t *seq);
+unsigned fiasco_amd_seq_gops(const fiasco_amd_seq_t *seq);
+unsigned fiasco_amd_seq_frames(const fiasco_amd_seq_t *seq);          /* in coding order */
+unsigned fiasco_amd_seq_gop_of(const fiasco_amd_seq_t *seq, unsigned frame);
+unsigned fiasco_amd_seq_ycol_size(const fiasco_amd_seq_t *seq);       /* 0 for gray streams */
+unsigned fiasco_amd_seq_initial_level(const fiasco_amd_seq_t *seq);
+int      fiasco_amd_seq_search(fiasco_amd_seq_t *seq, const unsigned *carry_in, const unsigned char *todo);
+int      fiasco_amd_seq_gop_result(const fiasco_amd_seq_t *seq, unsigned gop, unsigned *carry_out, int *failed);
+const unsigned char *fiasco_amd_seq_ycol(const fiasco_amd_seq_t *seq, unsigned frame);
+int      fiasco_amd_seq_write(fiasco_amd_seq_t *seq, unsigned frame, const unsigned char *ycol,
+                              unsigned char **out, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,48 @@
+"""BASELINE config 5 on the device: N-frame 1280x720 colour sequence (SURVEY App. C k-generator,
+x shifted by 3 px per frame), pattern ippppppppp, --prediction, block levels 6..10.
+usage: gpu_config5.py [frames] [check_frames]   (check_frames: prefix also run through the oracle)
+Prints one JSON line: frames/s of fiasco_coder() on the device (file I/O included)."""
+import hashlib, json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multiprocessing as mp
+import synth
+
+def make(args):
+    f, path = args
+    synth.write_ppm(path, synth.synth_color_k(1280, 720, 1234, 3 * f))
+    return path
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    ncheck = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    td = tempfile.mkdtemp()
+    with mp.get_context("fork").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        paths = pool.map(make, [(f, os.path.join(td, "v%03d.ppm" % f)) for f in range(n)])
+    import fiasco_amd
+    lib = fiasco_amd.library(); lib.set_verbosity(0)
+    o = lib.cli_options(); o.set_prediction(1, 6, 10)
+    out = os.path.join(td, "dev.fco")
+    res = {}
+    if n >= 3:                                   # SURVEY App. C known answer of the reference
+        assert lib.fiasco_coder(paths[:3], out, 20.0, o) == 1, lib.error_message()
+        res["v0[0-2] md5 == reference"] = hashlib.md5(open(out, "rb").read()).hexdigest() == "2528889c0453c4590289ad07d9fb87e3"
+    t0 = time.time()
+    assert lib.fiasco_coder(paths, out, 20.0, o) == 1, lib.error_message()
+    dt = time.time() - t0
+    data = open(out, "rb").read()
+    res.update({"workload": "%d frames 1280x720 colour, ippppppppp, --prediction" % n, "seconds": dt,
+                "frames_per_s": n / dt, "bytes": len(data), "md5": hashlib.md5(data).hexdigest()})
+    if ncheck:
+        ora = fiasco_amd.Library(os.path.join(ROOT, "oracle", "liboracle_fiasco.so")); ora.set_verbosity(0)
+        oo = ora.cli_options(); oo.set_prediction(1, 6, 10)
+        a, b = os.path.join(td, "a.fco"), os.path.join(td, "b.fco")
+        t0 = time.time()
+        assert ora.fiasco_coder(paths[:ncheck], a, 20.0, oo) == 1, ora.error_message()
+        res["oracle_seconds_%d_frames" % ncheck] = time.time() - t0
+        assert lib.fiasco_coder(paths[:ncheck], b, 20.0, o) == 1, lib.error_message()
+        res["device == oracle on the first %d frames" % ncheck] = open(a, "rb").read() == open(b, "rb").read()
+    print(json.dumps(res))
+
+if __name__ == "__main__":
+    main()

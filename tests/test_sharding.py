@@ -68,3 +68,55 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["dry_run"] is True and j["scaling"] == "weak"
     assert j["config"]["parallelism"] == "frames x2"
+
+
+def _seq_worker(rank, world, port, paths, pattern, pred, want, oracle_lib):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import fiasco_amd
+    from fiasco_amd.sharding import encode_sequence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = fiasco_amd.Library(oracle_lib)
+    lib.set_verbosity(0)
+    o = lib.cli_options(pattern=pattern)
+    o.set_prediction(1 if pred else 0, 6, 10)
+    got = encode_sequence(lib, [open(p, "rb").read() for p in paths], 20.0, o, device="cpu")
+    dist.barrier()
+    assert got == want, "rank %d: %d bytes, expected %d" % (rank, len(got), len(want))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("names,pattern,pred,golden", [
+    # colour all-intra: every frame is a GOP, the minimum level ratchets after the first frame --
+    # the speculation of the first sweep is WRONG for the later GOPs and they are searched again
+    (["c256", "c256b"], "i", 0, "seq2_color_i"),
+    (["c256b", "c256"], "i", 0, "seq2_color_i_rev"),
+    # y_column flags that show through from frame to frame (found by the fuzzer)
+    (["carry48_a", "carry48_b", "carry48_c"], None, 0, "seq3_color_carry48"),
+    # P frames: two GOPs of two frames
+    (["m0_128x96", "m1_128x96", "m2_128x96", "m3_128x96"], "ipip", 1, None),
+    (["c256", "c256b", "c256c", "c256"], "ipip", 0, None),
+])
+def test_two_rank_gop_sharding_with_speculation(oracle, manifest, inputs, tmp_path, names, pattern, pred, golden):
+    """GOPs of one sequence over 2 ranks (gloo): speculate-and-verify of the minimum level chain,
+    y_column chain resolved after a gather -- the stream is the one a single fiasco_coder() call
+    writes (and, where the real reference produced it, the reference's)."""
+    from conftest import ORACLE_LIB, options_from_args
+    paths = [inputs.path(n) for n in names]
+    if golden:
+        case = [c for c in manifest["cases"] if c["name"] == golden][0]
+        q, o = options_from_args(oracle, case["args"])
+        assert q == 20.0 or golden.startswith("seq3")
+    if golden and golden.startswith("seq3"):
+        pytest.skip("non-default options: covered through fiasco_coder() in test_oracle_pins")
+    o = oracle.cli_options(pattern=pattern or "i")
+    o.set_prediction(1 if pred else 0, 6, 10)
+    out = str(tmp_path / "single.fco")
+    assert oracle.fiasco_coder(paths, out, 20.0, o) == 1, oracle.error_message()
+    want = open(out, "rb").read()
+    if golden:
+        import hashlib
+        assert hashlib.md5(want).hexdigest() == case["md5"]        # the real reference's stream
+    mp.spawn(_seq_worker, args=(2, 29533, paths, pattern or "i", pred, want, ORACLE_LIB), nprocs=2, join=True)

@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_seq_open", "fiasco_amd_seq_free", "fiasco_amd_seq_gops", "fiasco_amd_seq_frames",
     "fiasco_amd_seq_gop_of", "fiasco_amd_seq_ycol_size", "fiasco_amd_seq_initial_level",
     "fiasco_amd_seq_search", "fiasco_amd_seq_gop_result", "fiasco_amd_seq_ycol", "fiasco_amd_seq_write",
+    "fiasco_amd_seq_probe",
 ]
 
 
@@ -326,6 +327,16 @@ class Sequence:
 
     def gop_of(self, frame):
         return self.L.fiasco_amd_seq_gop_of(self.handle, frame)
+
+    def probe(self):
+        """Level to speculate for the GOPs behind the first: what frame 0 alone leaves."""
+        c = ctypes
+        self.L.fiasco_amd_seq_probe.argtypes = [c.c_void_p, c.POINTER(c.c_uint)]
+        self.L.fiasco_amd_seq_probe.restype = c.c_int
+        lv = c.c_uint()
+        if not self.L.fiasco_amd_seq_probe(self.handle, lv):
+            raise FiascoError(self.lib.error_message())
+        return lv.value
 
     def search(self, carry_in, todo):
         c = ctypes

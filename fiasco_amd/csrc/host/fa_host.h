@@ -260,6 +260,7 @@ fa_seq *fa_seq_open(const fa_options *op, float quality, unsigned nframes, const
                     const size_t *lens, char const *const *names, unsigned rank, unsigned world);
 void    fa_seq_free(fa_seq *s);
 int     fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo);
+int     fa_seq_probe(fa_seq *s, unsigned *level);
 int     fa_seq_encode_all(fa_seq *s, fa_bitw *out,
                           void (*report)(const fa_wfa *, const fa_stats *, const fa_info *));
 unsigned fa_seq_gops(const fa_seq *s);

@@ -296,6 +296,28 @@ out:
     return rc;
 }
 
+/* The level to speculate for the GOPs behind the first one: what the very first frame (always an
+ * I frame) leaves -- the ratchet usually settles there.  One extra frame through the core
+ * instead of a second sweep over all GOPs; gray streams never change the level. */
+int fa_seq_probe(fa_seq *s, unsigned *level)
+{
+    fa_job job;
+    fa_image *im;
+    int ok;
+    *level = s->cp.lc_min_level;
+    if (!s->color || s->ngop < 2) return 1;
+    im = fa_image_from_pnm(s->bufs[s->order[0]], s->lens[s->order[0]], s->names ? s->names[s->order[0]] : "<memory>");
+    if (!im) return 0;
+    memset(&job, 0, sizeof job);
+    job.image = im; job.cp = s->cp; job.frame_type = FA_I_FRAME;
+    job.wfa = fa_wfa_alloc(s->cp.limit_states);
+    ok = job.wfa && fa_load_basis(s->op->basis_name, job.wfa) && job.wfa->states < s->cp.limit_states
+         && fa_core_encode_frames(1, &job) == 1;
+    if (ok) *level = job.lc_min_level_out;
+    fa_wfa_free(job.wfa); fa_image_free(im);
+    return 1;                                  /* a failing first frame shows up in the sweep */
+}
+
 /* y_column of coded frame k as the core left it: YCOL_UNSET where the frame wrote nothing */
 const uint8_t *fa_seq_ycol_raw(const fa_seq *s, unsigned k)
 {
@@ -329,7 +351,11 @@ int fa_seq_encode_all(fa_seq *s, fa_bitw *out, void (*report)(const fa_wfa *, co
     unsigned g, k, first_invalid = 0;
     int rc = 0, pass;
     if (!carry || !todo) { fa_set_error("Out of memory!"); goto out; }
-    for (g = 0; g < s->ngop; g++) { carry[g] = s->cp.lc_min_level; todo[g] = 1; }
+    {
+        unsigned guess;
+        if (!fa_seq_probe(s, &guess)) goto out;
+        for (g = 0; g < s->ngop; g++) { carry[g] = g ? guess : s->cp.lc_min_level; todo[g] = 1; }
+    }
     for (pass = 0; ; pass++) {
         unsigned t = s->cp.lc_min_level;
         if (!fa_seq_search(s, carry, todo)) goto out;
@@ -389,6 +415,7 @@ void fiasco_amd_seq_free(fiasco_amd_seq_t *q)
     free(q);
 }
 
+int fiasco_amd_seq_probe(fiasco_amd_seq_t *q, unsigned *level) { return fa_seq_probe(q->s, level); }
 unsigned fiasco_amd_seq_gops(const fiasco_amd_seq_t *q) { return q->s->ngop; }
 unsigned fiasco_amd_seq_frames(const fiasco_amd_seq_t *q) { return q->s->ncoded; }
 unsigned fiasco_amd_seq_ycol_size(const fiasco_amd_seq_t *q) { return q->s->color ? q->s->cap2 : 0; }

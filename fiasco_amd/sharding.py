@@ -62,7 +62,9 @@ def encode_sequence(lib, pnm_list, quality=20.0, options=None, device="cpu", gro
     seq = fiasco_amd.Sequence(lib, pnm_list, quality, options, rank, world)
     try:
         G, K = seq.gops, seq.frames
-        carry = [seq.initial_level] * G
+        # every rank probes the first frame itself: the same guess everywhere, nothing to send
+        guess = seq.probe()
+        carry = [seq.initial_level] + [guess] * (G - 1)
         todo = [True] * G
         used, left, failed = [0] * G, [0] * G, [False] * G
         for _ in range(64):

@@ -179,6 +179,8 @@ unsigned fiasco_amd_seq_frames(const fiasco_amd_seq_t *seq);          /* in codi
 unsigned fiasco_amd_seq_gop_of(const fiasco_amd_seq_t *seq, unsigned frame);
 unsigned fiasco_amd_seq_ycol_size(const fiasco_amd_seq_t *seq);       /* 0 for gray streams */
 unsigned fiasco_amd_seq_initial_level(const fiasco_amd_seq_t *seq);
+/* the level worth speculating for every GOP but the first: what the first frame alone leaves */
+int      fiasco_amd_seq_probe(fiasco_amd_seq_t *seq, unsigned *level);
 int      fiasco_amd_seq_search(fiasco_amd_seq_t *seq, const unsigned *carry_in, const unsigned char *todo);
 int      fiasco_amd_seq_gop_result(const fiasco_amd_seq_t *seq, unsigned gop, unsigned *carry_out, int *failed);
 const unsigned char *fiasco_amd_seq_ycol(const fiasco_amd_seq_t *seq, unsigned frame);

@@ -266,3 +266,33 @@ def test_stage1_pricing_restructuring(tmp_path):
     out = subprocess.run([exe, "400000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert " 0 mismatches" in out.stdout
+
+
+def test_unmodified_reference_cli_links_against_this_library(product, oracle, inputs, tmp_path):
+    """INTEGRATION.md 1 as a test: the object files of the UNMODIFIED reference CLI
+    (bin/cwfa.c, params.c, binerror.c, getopt*.c, compiled by oracle/ref_build.sh) link against
+    libfiasco_amd.so with no unresolved symbol, and -- linked against the oracle library, which
+    shares every line of host code with the product -- produce the reference's golden stream."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = [os.path.join(root, "oracle", "_ref", "obj", "bin_%s.o" % n)
+            for n in ("cwfa", "params", "binerror", "getopt", "getopt1")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("reference objects not built here (oracle/ref_build.sh needs /root/reference)")
+    exe = str(tmp_path / "cfiasco_product")
+    r = subprocess.run(["gcc", "-o", exe] + objs + ["-L" + os.path.join(root, "fiasco_amd"), "-lfiasco_amd",
+                        "-Wl,-rpath," + os.path.join(root, "fiasco_amd"), "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr                       # no unresolved symbol
+    env = dict(os.environ, FIASCO_DATA=os.path.join(root, "fiasco_amd", "data"))
+    if not os.path.exists("/dev/kfd"):
+        out = subprocess.run([exe, "--progress-meter", "0", "-o", str(tmp_path / "p.fco"), inputs.path("g256")],
+                             env=env, capture_output=True, text=True)
+        assert out.returncode != 0 and "no HIP device" in out.stderr     # loud, no fallback
+    exe2 = str(tmp_path / "cfiasco_oracle_cli")
+    r = subprocess.run(["gcc", "-o", exe2] + objs + ["-L" + os.path.join(root, "oracle"), "-loracle_fiasco",
+                        "-Wl,-rpath," + os.path.join(root, "oracle"), "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe2, "--progress-meter", "0", "-o", str(tmp_path / "o.fco"), inputs.path("g256")],
+                         env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    golden = open(os.path.join(root, "tests", "golden", "g256_q20.fco"), "rb").read()
+    assert (tmp_path / "o.fco").read_bytes() == golden

@@ -236,7 +236,6 @@ struct Sh {
     double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM], lglv_m1;
     float    Ltab[MAXED + 1];
     float    Q0, Q1;
-    float    tb[2];                /* tree_bits (LEAF, CHILD) of the level being approximated */
     MPState  mp;
 #if FC_VARIANT_BIG
     MPState  mp_keep;              /* best result so far of a call with retries */
@@ -1501,8 +1500,6 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
     }
 }
 
-__device__ float tree_bits_dev(const Sh &sh, int ML, int child, int level, int which);
-
 #include "mp_device.inc"
 
 /* ------------------------------------------------------------------ serial state machine */
@@ -1789,9 +1786,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             if (rg.level <= sh.par.lc_max) {
                 fr.lrange = rg;
                 fr.lrange.tree = RANGE_;
-#if FC_VARIANT_BIG
                 fr.lrange.tree_bits = tree_bits_dev(sh, ML, 0, rg.level, 0);
-#endif                              /* default build: priced by two idle lanes inside OP_APPROX (sh.tb) */
                 fr.lrange.matrix_bits = 0;
                 fr.lrange.weights_bits = 0;
 #if FC_VARIANT_BIG
@@ -1819,23 +1814,17 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 snap_load(F, sh, sh.sp, 0);
             }
             if (rg.level > sh.lc_min) {
-#if FC_VARIANT_BIG
                 Range z;
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
                 for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
                 z.err = z.tree_bits = z.matrix_bits = z.weights_bits = 0;
+#if FC_VARIANT_BIG
                 z.nd_tree_bits = z.nd_weights_bits = z.mv_tree_bits = z.mv_coord_bits = 0; z.prediction = 0;
                 for (int i = 0; i < 5; i++) z.mv[i] = 0;
-                fr.child[0] = z; fr.child[1] = z;
-#endif                              /* default build: a child is either written as a whole by its own
-                                     * search (pop) or never looked at (the loop ends with MAXCOSTS) */
-                fr.rrange = rg;
-#if FC_VARIANT_BIG
-                fr.rrange.tree_bits = tree_bits_dev(sh, ML, 1, rg.level, 0);
-#else
-                /* the tree model has not changed since the node's OP_APPROX priced both symbols */
-                fr.rrange.tree_bits = rg.level <= sh.par.lc_max ? sh.tb[1] : tree_bits_dev(sh, ML, 1, rg.level, 0);
 #endif
+                fr.child[0] = z; fr.child[1] = z;
+                fr.rrange = rg;
+                fr.rrange.tree_bits = tree_bits_dev(sh, ML, 1, rg.level, 0);
                 fr.rrange.matrix_bits = 0;
                 fr.rrange.weights_bits = 0;
                 fr.rrange.err = 0;

@@ -249,6 +249,10 @@ struct Sh {
         unsigned long long bytes_mp, bytes_img, bytes_gram, n_mp, n_steps, n_blocks, n_appends,
                            n_fulleval, n_blockevals, t_mpA, t_mpB;
     } cnt;                         /* DevFrame counters of the same names */
+#ifdef FC_PM
+    unsigned long long pm[8], pm_t;
+    int pm_prev;
+#endif
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tk_ph[8], ph_t0, tk_init[2], tk_apx[4];
     int      ph_prev;
@@ -1500,6 +1504,13 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
     }
 }
 
+#ifdef FC_PM
+#define PM0(sh) do { (sh).pm_t = wall_clock64(); } while (0)
+#define PM(sh, i, g) do { if (FC_PM == (g)) { unsigned long long t_ = wall_clock64(); (sh).pm[i] += t_ - (sh).pm_t; (sh).pm_t = t_; } } while (0)
+#else
+#define PM0(sh) do { } while (0)
+#define PM(sh, i, g) do { } while (0)
+#endif
 #include "mp_device.inc"
 
 /* ------------------------------------------------------------------ serial state machine */
@@ -1711,17 +1722,24 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
     return 1;
 }
 
-/* advance the partition search until a data-parallel operation is required */
-__device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+/* One transition of the state machine per call; 1 = call again, 0 = sh.op holds the next parallel
+ * operation (or OP_DONE).  One transition per call on purpose: as a loop inside one function the
+ * compiler hoists every constant and LDS address of every phase into registers for the whole
+ * loop, ~120 VGPRs, and the function then saves and restores 48 callee-saved registers through
+ * scratch memory on every call (a memory round trip on the serial path, ~100 k times per frame). */
+__device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 {
     const int ML = sh.par.ML;
-    for (;;) {
+    {
         if (sh.sp < 0) {
-            if (!band_advance(F, sh)) { sh.op = OP_DONE; return; }
-            if (sh.op == OP_CHROMA) return;
-            continue;
+            if (!band_advance(F, sh)) { sh.op = OP_DONE; return 0; }
+            if (sh.op == OP_CHROMA) return 0;
+            return 1;
         }
         SFrame &fr = sh.st[sh.sp];
+#if defined(FC_PM) && FC_PM == 3
+        { unsigned long long t_ = wall_clock64(); sh.pm[sh.pm_prev & 7] += t_ - sh.pm_t; sh.pm_t = t_; sh.pm_prev = fr.phase; }
+#endif
 #ifdef FC_SERIAL_PROFILE
         {   /* developer profile: ticks per phase of the state machine (previous phase ends here) */
             unsigned long long t = wall_clock64();
@@ -1753,7 +1771,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             if (rg.level == sh.par.lc_max) {
                 rg.address = rg.image = 0;
                 sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
-                return;
+                return 0;
             }
             break;
         }
@@ -1795,7 +1813,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 fr.lrange.mv_coord_bits = 0;
 #endif
                 sh.op = OP_APPROX;
-                return;
+                return 0;
             }
             fr.lincomb = MAXCOSTS;
             break;
@@ -1862,7 +1880,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             if (label && rr.level <= sh.par.lc_max && sh.states > fr.states && !sh.band) {
                 sh.op = OP_IPIS_INCR; sh.a0 = ch.image; sh.a1 = ch.address; sh.a2 = ch.level;
                 sh.a3 = fr.states;
-                return;
+                return 0;
             }
             break;
         }
@@ -1899,7 +1917,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 sh.a2 = (fr.ret < 0 && c0.level >= F.p_min) ? c0.level : -1;
                 sh.a3 = c0.x | (c0.y << 16);
                 fr.norm_first = 0; fr.norm_done = 1;
-                return;
+                return 0;
             }
             fr.norm_done = 0;
 #endif
@@ -1973,7 +1991,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
                 store_new_state(F, sh, fr, aux);
                 fr.phase = PH_AFTER_APPEND;
-                if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return; }
+                if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return 0; }
                 break;
             }
         }
@@ -2005,7 +2023,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 sh.op = OP_MC_SEARCH; sh.a0 = rg.level; sh.a1 = rg.x | (rg.y << 16);
                 sh.a2 = (rg.level == F.p_min ? 1 : 0) | (rg.level > F.p_min && fr.norm_first ? 2 : 0);
                 fr.phase = PH_PRED_MC2;
-                return;
+                return 0;
             }
             {   /* the range's DC part in the DC format of the normal model */
                 const float x = rg.level > il ? sh.par.ipis[(size_t) rg.image * P]
@@ -2037,7 +2055,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
                 else {
                     sh.op = OP_PRED_SETUP; sh.a0 = fr.rg.level; sh.a1 = fr.rg.address;
                     fr.phase = PH_PRED_RECURSE;
-                    return;
+                    return 0;
                 }
             }
             /* no residual search: everything back as the recursion left it */
@@ -2071,7 +2089,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
             sh.op = OP_PRED_FINISH; sh.a0 = keep;
             fr.phase = PH_PRED_DONE;
             fr.label = keep;                 /* remembered for PH_PRED_DONE */
-            return;
+            return 0;
         }
         case PH_PRED_DONE: {
             Range &rg = fr.rg;
@@ -2106,7 +2124,7 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         }
 #endif
         }
-        continue;
+        return 1;
     pop:
         if (sh.sp > 0) {
             SFrame &pf = sh.st[sh.sp - 1];
@@ -2119,6 +2137,14 @@ __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__rest
         }
         sh.sp--;
     }
+    return 1;
+}
+
+/* advance the partition search until a data-parallel operation is required */
+__device__ __forceinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    while (serial_step(F, sh))
+        ;
 }
 
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
@@ -2304,6 +2330,9 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; for (int k = 0; k < 4; k++) sh.tk_apx[k] = 0; }
 #endif
+#ifdef FC_PM
+    if (tid == 0) for (int k = 0; k < 8; k++) sh.pm[k] = 0;
+#endif
     unsigned long long t_begin = wall_clock64();
     /* everything below is inlined into this one loop (a single call site per op keeps the
      * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
@@ -2334,7 +2363,13 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
 #ifdef FC_SERIAL_PROFILE
             sh.ph_t0 = t1;
 #endif
+#if defined(FC_PM) && FC_PM == 3
+            sh.pm_t = wall_clock64(); sh.pm_prev = 7;
+#endif
             serial_advance(F, sh);
+#if defined(FC_PM) && FC_PM == 3
+            { unsigned long long t_ = wall_clock64(); sh.pm[sh.pm_prev & 7] += t_ - sh.pm_t; }
+#endif
 #ifdef FC_SERIAL_PROFILE
             { unsigned long long t = wall_clock64(); sh.tk_ph[sh.ph_prev] += t - sh.ph_t0; }
 #endif
@@ -2356,6 +2391,9 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         F.dbg[3] = sh.tk_apx[0]; F.dbg[4] = sh.tk_apx[1]; F.dbg[5] = sh.tk_apx[2]; F.dbg[2] = sh.tk_apx[3];
 #endif
     }
+#ifdef FC_PM
+    if (tid == 0) for (int k = 0; k < 8; k++) F.dbg[k] = sh.pm[k];
+#endif
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */
         F.states = sh.states;

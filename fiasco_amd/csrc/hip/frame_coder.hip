@@ -236,6 +236,7 @@ struct Sh {
     double   lgdc[FC_MAXSYM], lglv[FC_MAXSYM], lglv_m1;
     float    Ltab[MAXED + 1];
     float    Q0, Q1;
+    float    tb[2];                /* default build: tree_bits (LEAF, CHILD) of the level being approximated (mp_tables) */
     MPState  mp;
 #if FC_VARIANT_BIG
     MPState  mp_keep;              /* best result so far of a call with retries */
@@ -1504,6 +1505,8 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
     }
 }
 
+__device__ float tree_bits_dev(const Sh &sh, int ML, int child, int level, int which);
+
 #ifdef FC_PM
 #define PM0(sh) do { (sh).pm_t = wall_clock64(); } while (0)
 #define PM(sh, i, g) do { if (FC_PM == (g)) { unsigned long long t_ = wall_clock64(); (sh).pm[i] += t_ - (sh).pm_t; (sh).pm_t = t_; } } while (0)
@@ -1804,7 +1807,9 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             if (rg.level <= sh.par.lc_max) {
                 fr.lrange = rg;
                 fr.lrange.tree = RANGE_;
+#if FC_VARIANT_BIG
                 fr.lrange.tree_bits = tree_bits_dev(sh, ML, 0, rg.level, 0);
+#endif                              /* default build: priced by an idle lane of OP_APPROX (mp_tables, sh.tb) */
                 fr.lrange.matrix_bits = 0;
                 fr.lrange.weights_bits = 0;
 #if FC_VARIANT_BIG
@@ -1842,7 +1847,13 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
 #endif
                 fr.child[0] = z; fr.child[1] = z;
                 fr.rrange = rg;
+#if FC_VARIANT_BIG
                 fr.rrange.tree_bits = tree_bits_dev(sh, ML, 1, rg.level, 0);
+#else
+                /* the tree model has not changed since the node's OP_APPROX priced both symbols
+                 * (only finished children update it) */
+                fr.rrange.tree_bits = rg.level <= sh.par.lc_max ? sh.tb[1] : tree_bits_dev(sh, ML, 1, rg.level, 0);
+#endif
                 fr.rrange.matrix_bits = 0;
                 fr.rrange.weights_bits = 0;
                 fr.rrange.err = 0;

@@ -1740,6 +1740,37 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             return 1;
         }
         SFrame &fr = sh.st[sh.sp];
+#if defined(FC_PM) && FC_PM == 4
+        /* developer micro-benchmark of the serial lane under the live load of the CU: every 1024th
+         * transition, 64 dependent LDS reads / 64 dependent float adds / 64 independent LDS reads /
+         * 64 dependent int ops; ticks (100 MHz) in pm[0..3], samples in pm[7] */
+        if ((sh.pm_prev++ & 1023) == 0) {
+            volatile int *chain = (volatile int *) sh.pixels;      /* scratch area of the block, unused here */
+            int keep[8];
+            for (int k = 0; k < 8; k++) keep[k] = chain[k];
+            for (int k = 0; k < 8; k++) chain[k] = (k + 1) & 7;
+            unsigned long long t0 = wall_clock64();
+            int idx = 0;
+            for (int k = 0; k < 64; k++) idx = chain[idx];
+            unsigned long long t1 = wall_clock64();
+            float a = __int_as_float(idx + 0x3f800000);
+            for (int k = 0; k < 64; k++) a = a + 1.25f;
+            asm volatile("" : "+v"(a));
+            unsigned long long t2 = wall_clock64();
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 64; k++) sum += chain[k & 7];
+            asm volatile("" : "+v"(sum));
+            unsigned long long t3 = wall_clock64();
+            int x = sum;
+            for (int k = 0; k < 64; k++) x = x * 3 + 1;
+            asm volatile("" : "+v"(x));
+            unsigned long long t4 = wall_clock64();
+            for (int k = 0; k < 8; k++) chain[k] = keep[k];
+            sh.pm[0] += t1 - t0; sh.pm[1] += t2 - t1; sh.pm[2] += t3 - t2; sh.pm[3] += t4 - t3;
+            sh.pm[7] += 1; sh.pm[6] += (unsigned long long) ((x & 1) + (__float_as_int(a) & 1));
+        }
+#endif
 #if defined(FC_PM) && FC_PM == 3
         { unsigned long long t_ = wall_clock64(); sh.pm[sh.pm_prev & 7] += t_ - sh.pm_t; sh.pm_t = t_; sh.pm_prev = fr.phase; }
 #endif

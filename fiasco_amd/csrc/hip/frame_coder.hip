@@ -1766,6 +1766,19 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             for (int k = 0; k < 64; k++) x = x * 3 + 1;
             asm volatile("" : "+v"(x));
             unsigned long long t4 = wall_clock64();
+            {   /* dependent global loads: 32 lines of the Gram table far apart (cold: HBM or L2),
+                 * then the same 32 again (warm: L1/L2) */
+                const volatile float *g = F.gram;
+                const size_t stride = (size_t) F.P * 8 + 64;
+                unsigned long long u0 = wall_clock64();
+                size_t o = (size_t) (x & 1);
+                for (int k = 0; k < 32; k++) { float v = g[o]; o = (size_t) (k + 1) * stride + (size_t) (__float_as_int(v) & 1); }
+                unsigned long long u1 = wall_clock64();
+                o = (size_t) (o & 1);
+                for (int k = 0; k < 32; k++) { float v = g[o]; o = (size_t) (k + 1) * stride + (size_t) (__float_as_int(v) & 1); }
+                unsigned long long u2 = wall_clock64();
+                sh.pm[4] += u1 - u0; sh.pm[5] += u2 - u1; sh.pm[6] += o & 1;
+            }
             for (int k = 0; k < 8; k++) chain[k] = keep[k];
             sh.pm[0] += t1 - t0; sh.pm[1] += t2 - t1; sh.pm[2] += t3 - t2; sh.pm[3] += t4 - t3;
             sh.pm[7] += 1; sh.pm[6] += (unsigned long long) ((x & 1) + (__float_as_int(a) & 1));

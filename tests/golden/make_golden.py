@@ -198,6 +198,20 @@ def make_input(name):
     raise ValueError(kind)
 
 
+# Streams of the real reference that take too long to regenerate with every run of this script:
+# produced once with the same binary (oracle/_ref/cfiasco_ref), command and generator recorded.
+LONG_KNOWN_ANSWERS = {
+    "config5_300": {
+        "frames": 300,
+        "generator": "synth.synth_color_k(1280, 720, 1234, 3 * f), f = 0..299 (tests/gpu_config5.py)",
+        "command": "cfiasco_ref --progress-meter 0 --prediction -o out.fco 'v[000-299].ppm'  "
+                   "(pattern ippppppppp, -q 20, block levels 6..10)",
+        "bytes": 1886498, "md5": "714a25c639d8daae598f84095f4856f7",
+        "produced_by": "oracle/_ref/cfiasco_ref, 68 min on one core; oracle/cfiasco_oracle gives the same stream",
+    },
+}
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("reference CLI missing: run oracle/ref_build.sh first")
@@ -261,6 +275,7 @@ def main():
             open(os.path.join(HERE, ent["file"]), "wb").write(data)
         man["video_cases"].append(ent)
         print("%-28s %6d B  %s" % (cname, len(data), ent["md5"]))
+    man["long_known_answers"] = LONG_KNOWN_ANSWERS
     json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1)
 
 

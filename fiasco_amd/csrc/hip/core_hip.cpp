@@ -23,10 +23,14 @@
 #include "frame_coder.h"
 #include "libfiasco_amd_hip.h"
 
-extern "C" void fc_launch(DevFrame *d_frames, unsigned n, hipStream_t stream);
-extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, hipStream_t stream);
-extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, hipStream_t stream);
-extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, hipStream_t stream);
+extern "C" void fc_launch(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, hipStream_t stream);
+extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, hipStream_t stream);
+extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, hipStream_t stream);
+extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, hipStream_t stream);
 
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
@@ -355,6 +359,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
                           int max_save, int inter, int plevels, int color)
 {
     Layout L;
+    memset(&L, 0, sizeof L);             /* compared with memcmp (frame queue) */
     size_t o = 0;
     L.max_save = max_save;
 #define CARVE(field, bytes) do { L.field = o; o = align_up(o + (bytes), 256); } while (0)
@@ -461,6 +466,7 @@ struct FrameSlot {
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
+    bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
     const int16_t *ext_next = nullptr;   /* ... of the frames the NEXT pass encodes */
@@ -503,6 +509,19 @@ struct Staged {
     bool   up_pending = false;
     hipStream_t ustream = nullptr;
     hipEvent_t  ev_up = nullptr;
+    /* frame queue (frame_coder.hip, FC_KERNEL): frames beyond the number of resident workgroups
+     * (or beyond what HBM holds in slabs) borrow the slab of whichever workgroup takes them */
+    int       lender0 = -1;        /* first slot with a slab of the queue's layout */
+    Layout    qL;                  /* that layout and capacity (the slot itself may be re-staged larger) */
+    int       qP = 0, qPA = 0;
+    size_t    lenders = 0, borrowers = 0, lender_cap = 0;
+    char     *qpix = nullptr;      /* pixel planes of the borrowers */
+    size_t    qpix_bytes = 0, qpix_used = 0;
+    unsigned long long *d_ring = nullptr;   /* free slabs in the order they were handed back, per kernel build */
+    size_t    ring_n = 0;
+    unsigned *d_queue = nullptr;   /* two counters per kernel build: tickets taken, slabs handed back */
+    unsigned *d_ptrmask = nullptr;
+    bool      ptrmask_ready = false;
 };
 
 static void fill_frame(FrameSlot &fs, const fa_job *job)
@@ -593,9 +612,83 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.sv_gram = (float *) (base + L.sv_gram); F.sv_img = (float *) (base + L.sv_img);
     F.sv_auto = (FcSavedRow *) (base + L.sv_auto);
     F.max_save = L.max_save;
+    F.slab_base = base; F.slab_bytes = L.total;
 }
 
 /* allocate the slab of one frame for capacity fs.P and upload its pixel plane */
+static void slot_layout(Staged *S, FrameSlot &fs)
+{
+    const fa_job *job = &S->jobs[fs.job];
+    const fa_cparams *cp = &job->cp;
+    int il = (int) cp->images_level;
+    int low = cp->lc_min_level < cp->images_level;
+    int NL = (int) (cp->lc_max_level - (low ? cp->lc_min_level : cp->images_level) + 1);
+    int NS = (int) fa_size_of_tree(cp->products_level);
+    int NA = 1 << (cp->lc_max_level - cp->images_level);
+    int NI = (int) fa_size_of_tree(cp->images_level);
+    size_t npix = (size_t) job->image->width * job->image->height;
+    const int bands = job->image->color ? 3 : 1;
+    int max_save = 0;
+    const int inter = job->frame_type;
+    if (cp->prediction || inter) {
+        int span = (int) cp->p_max_level - (int) cp->lc_min_level + 1;
+        max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
+    }
+    fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0);
+}
+
+/* ---- frame queue: which frames may share slabs ---- */
+
+static bool queue_eligible(const Staged *S, const FrameSlot &fs)
+{
+    const fa_job *job = &S->jobs[fs.job];
+    return !fs.big && job->frame_type == FA_I_FRAME && !job->ycol_carry && !getenv("FIASCO_AMD_NO_QUEUE");
+}
+
+/* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
+static bool queue_layout(const Staged *S, const FrameSlot &fs)
+{
+    if (S->lender0 < 0) return false;
+    return fs.P == S->qP && fs.PA == S->qPA && memcmp(&fs.L, &S->qL, sizeof(Layout)) == 0;
+}
+
+static void fill_frame(FrameSlot &fs, const fa_job *job);
+
+/* a frame without a slab: descriptor laid out for the slab of the queue's first frame (the
+ * workgroup that takes it re-bases the pointers), pixel planes in the queue's pixel buffer */
+static int stage_borrower(Staged *S, FrameSlot &fs, size_t frames_left)
+{
+    fa_job *job = &S->jobs[fs.job];
+    const FrameSlot &ref = S->slots[S->lender0];
+    const size_t npix = (size_t) job->image->width * job->image->height;
+    const int bands = job->image->color ? 3 : 1;
+    const size_t need = align_up(npix * bands * 2, 256);
+    if (!S->qpix) {
+        size_t bytes = need * frames_left;
+        if (hipMalloc((void **) &S->qpix, bytes) != hipSuccess) { S->qpix = nullptr; (void) hipGetLastError(); return 0; }
+        S->qpix_bytes = bytes; S->qpix_used = 0;
+    }
+    if (S->qpix_used + need > S->qpix_bytes) return 0;
+    fs.base = ref.base;                       /* the layout reference, not an owned slab */
+    fill_frame(fs, job);
+    fs.base = nullptr; fs.bytes = 0;
+    fs.borrow = true;
+    fs.ext_pix = (const int16_t *) (S->qpix + S->qpix_used);
+    fs.F.pix16 = fs.ext_pix;
+    for (int b = 0; b < bands; b++)
+        if (hipMemcpyAsync(S->qpix + S->qpix_used + (size_t) b * npix * 2, job->image->pixels[b], npix * 2,
+                           hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
+            fs.borrow = false; fs.ext_pix = nullptr;
+            return 0;
+        }
+    S->qpix_used += need;
+    S->borrowers++;
+    fs.staged = true;
+    return 1;
+}
+
 static int stage_slot(Staged *S, FrameSlot &fs)
 {
     fa_job *job = &S->jobs[fs.job];
@@ -686,6 +779,10 @@ extern "C" void fa_core_unstage(void *h)
     for (size_t k = 0; k < S->slots.size(); k++)
         if (S->slots[k].base) slab_release(S->slots[k].base, S->slots[k].bytes);
     if (S->d_frames) (void) hipFree(S->d_frames);
+    if (S->qpix) (void) hipFree(S->qpix);
+    if (S->d_ring) (void) hipFree(S->d_ring);
+    if (S->d_queue) (void) hipFree(S->d_queue);
+    if (S->d_ptrmask) (void) hipFree(S->d_ptrmask);
     if (S->cstream) { (void) hipStreamSynchronize(S->cstream); (void) hipStreamDestroy(S->cstream); }
     for (int i = 0; i < 2; i++) if (S->d_pack[i]) (void) hipFree(S->d_pack[i]);
     if (S->pinned) (void) hipHostFree(S->pinned);
@@ -738,14 +835,44 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         if (fs.PA < fs.P) fs.PA = fs.P;
         S->slots.push_back(fs);
     }
-    /* stage as many frames as HBM holds; the rest is staged by run() as slabs free up */
+    /* Stage the frames.  Every frame gets a slab of its own until the device is full -- as many
+     * frames of one layout as the chip runs workgroups at once, or as HBM holds; the frames
+     * after that join the FRAME QUEUE of that layout (no slab: whichever workgroup finishes its
+     * frame takes the next one into its slab).  What can neither have a slab nor join the queue
+     * is staged by run() as slabs free up. */
+    int cus = 0;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
     for (size_t k = 0; k < S->slots.size(); k++) {
-        if (!stage_slot(S, S->slots[k])) {
-            if (S->slots[k].rejected) continue;   /* outside the device scope: message recorded */
-            if (k == 0) continue;          /* does not fit even alone: error already recorded */
-            S->jobs[S->slots[k].job].errmsg[0] = 0;   /* later wave */
-            break;
+        FrameSlot &fs = S->slots[k];
+        const bool elig = queue_eligible(S, fs);
+        slot_layout(S, fs);
+        if (elig && queue_layout(S, fs) && S->lenders >= S->lender_cap
+            && stage_borrower(S, fs, S->slots.size() - k))
+            continue;
+        if (stage_slot(S, fs)) {
+            if (elig && S->lender0 < 0) {
+                S->lender0 = (int) k; S->lenders = 1;
+                S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA;
+                /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
+                 * launch will use (512-thread build for P > 3072: one per CU) */
+                S->lender_cap = (size_t) cus * (fs.P > 12 * 256 ? 1 : 4);
+                if (getenv("FIASCO_AMD_QUEUE_SLABS") && atoi(getenv("FIASCO_AMD_QUEUE_SLABS")) > 0)
+                    S->lender_cap = (size_t) atoi(getenv("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
+            } else if (elig && queue_layout(S, fs)) S->lenders++;
+            continue;
         }
+        if (fs.rejected) continue;         /* outside the device scope: message recorded */
+        if (elig && queue_layout(S, fs) && S->lenders >= 1) {     /* HBM is full: queue */
+            S->jobs[fs.job].errmsg[0] = 0;
+            if (stage_borrower(S, fs, S->slots.size() - k)) { S->lender_cap = S->lenders; continue; }
+        }
+        if (k == 0) continue;              /* does not fit even alone: error already recorded */
+        S->jobs[fs.job].errmsg[0] = 0;     /* later wave */
+        break;
     }
     (void) hipStreamSynchronize(S->stream);
     S->ok = true;
@@ -932,6 +1059,41 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     return 1;
 }
 
+/* device-side state of the frame queue: the ring of free slabs, the counters, and the map
+ * of the descriptor's slab pointers (one bit per 8-byte word): the words that move with the base
+ * when the same frame is laid out for two different slabs, plus pack_src */
+static bool queue_resources(Staged *S, size_t frames)
+{
+    if (4 * frames > S->ring_n) {
+        if (S->d_ring) (void) hipFree(S->d_ring);
+        S->d_ring = nullptr; S->ring_n = 0;
+        if (hipMalloc((void **) &S->d_ring, sizeof(unsigned long long) * 4 * frames) != hipSuccess) { (void) hipGetLastError(); return false; }
+        S->ring_n = 4 * frames;
+    }
+    if (!S->d_queue && hipMalloc((void **) &S->d_queue, 8 * sizeof(unsigned)) != hipSuccess) {
+        S->d_queue = nullptr; (void) hipGetLastError(); return false;
+    }
+    if (!S->ptrmask_ready) {
+        const size_t words = FC_DESC_WORDS, mwords = (words + 31) / 32;
+        std::vector<unsigned> mask(mwords, 0u);
+        FrameSlot a = S->slots[S->lender0], b = S->slots[S->lender0];
+        const fa_job *job = &S->jobs[a.job];
+        b.base = a.base + (1u << 24);
+        fill_frame(a, job); fill_frame(b, job);
+        const unsigned long long *wa = (const unsigned long long *) &a.F, *wb = (const unsigned long long *) &b.F;
+        for (size_t w = 0; w < sizeof(DevFrame) / 8; w++)
+            if (wa[w] != wb[w]) mask[w >> 5] |= 1u << (w & 31);
+        const size_t wp = offsetof(DevFrame, pack_src) / 8;
+        mask[wp >> 5] |= 1u << (wp & 31);
+        if (!S->d_ptrmask && hipMalloc((void **) &S->d_ptrmask, mwords * sizeof(unsigned)) != hipSuccess) {
+            S->d_ptrmask = nullptr; (void) hipGetLastError(); return false;
+        }
+        if (hipMemcpy(S->d_ptrmask, mask.data(), mwords * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) return false;
+        S->ptrmask_ready = true;
+    }
+    return true;
+}
+
 /* build the next launch from the frames that are staged and not yet encoded, upload their
  * descriptors and start the kernel(s); nothing is waited for.  Returns false when there is
  * nothing to launch. */
@@ -946,20 +1108,29 @@ static bool launch_wave(Staged *S)
      * {256, 512 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[4] = { 0, 0, 0, 0 };
+    size_t group_n[4] = { 0, 0, 0, 0 }, group_lend[4] = { 0, 0, 0, 0 }, group_borrow[4] = { 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
         const bool few = batch.size() <= (size_t) cus && !getenv("FIASCO_AMD_NO_WIDE");
+        /* per build: first the frames of the queue's layout -- those with a slab (the queue's
+         * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
         for (int g = 0; g < 4; g++)
-            for (size_t b = 0; b < batch.size(); b++) {
-                const FrameSlot &fs = S->slots[batch[b]];
-                const bool wide = few || fs.P > 12 * 256;
-                if ((int) fs.big * 2 + (int) wide == g) { ordered.push_back(batch[b]); group_n[g]++; }
-            }
+            for (int part = 0; part < 3; part++)
+                for (size_t b = 0; b < batch.size(); b++) {
+                    const FrameSlot &fs = S->slots[batch[b]];
+                    const bool wide = few || fs.P > 12 * 256;
+                    if ((int) fs.big * 2 + (int) wide != g) continue;
+                    const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
+                    const int where = fs.borrow ? 1 : q ? 0 : 2;
+                    if (where != part) continue;
+                    ordered.push_back(batch[b]);
+                    group_n[g]++;
+                    if (part == 0) group_lend[g]++; else if (part == 1) group_borrow[g]++;
+                }
         batch.swap(ordered);
     }
     std::vector<DevFrame> &hf = S->hf;
@@ -991,7 +1162,7 @@ static bool launch_wave(Staged *S)
         S->packed = pack != nullptr && S->cstream != nullptr;
         for (size_t b = 0; b < batch.size(); b++) {
             const FrameSlot &fs = S->slots[batch[b]];
-            hf[b].pack_src = fs.base + fs.L.tree;
+            hf[b].pack_src = fs.F.slab_base + fs.L.tree;     /* a borrower's is re-based by the kernel */
             hf[b].pack_bytes = (unsigned) (fs.L.pool_states - fs.L.tree);
             hf[b].pack_dst = S->packed ? pack + S->pack_off[b] : nullptr;
         }
@@ -1004,11 +1175,30 @@ static bool launch_wave(Staged *S)
     /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
     fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
     {
-        typedef void (*launch_fn)(DevFrame *, unsigned, hipStream_t);
+        typedef void (*launch_fn)(DevFrame *, unsigned, unsigned, unsigned long long *, unsigned *, const unsigned *, hipStream_t);
         static const launch_fn launch[4] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide };
         size_t first = 0;
         for (int g = 0; g < 4 && !fail; g++) {
-            if (group_n[g]) launch[g](S->d_frames + first, (unsigned) group_n[g], S->stream);
+            size_t plain = group_n[g], at = first;
+            if (group_borrow[g]) {
+                /* the queue: group_lend[g] frames with slabs first, then the frames that borrow one */
+                const size_t nq = group_lend[g] + group_borrow[g];
+                if (!group_lend[g] || !S->packed || !queue_resources(S, batch.size())) {
+                    for (size_t b = at + group_lend[g]; b < at + nq; b++) hf[b].status = FC_ERR_INTERNAL;
+                    fail = fail || hipMemcpyAsync(S->d_frames + at, hf.data() + at, sizeof(DevFrame) * nq,
+                                                  hipMemcpyHostToDevice, S->stream) != hipSuccess;
+                    if (group_lend[g])
+                        launch[g](S->d_frames + at, (unsigned) group_lend[g], (unsigned) group_lend[g], nullptr, nullptr, nullptr, S->stream);
+                } else {
+                    unsigned long long *ring = S->d_ring + (size_t) g * batch.size();
+                    fail = fail || hipMemsetAsync(S->d_queue + 2 * g, 0, 2 * sizeof(unsigned), S->stream) != hipSuccess;
+                    fail = fail || hipMemsetAsync(ring, 0, nq * sizeof(unsigned long long), S->stream) != hipSuccess;
+                    launch[g](S->d_frames + at, (unsigned) nq, (unsigned) group_lend[g], ring, S->d_queue + 2 * g,
+                              S->d_ptrmask, S->stream);
+                }
+                at += nq; plain -= nq;
+            }
+            if (plain) launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, S->stream);
             first += group_n[g];
         }
     }
@@ -1108,7 +1298,8 @@ static void complete_wave(Staged *S)
             /* capacity guess too small: bigger slab, same inputs, encode again */
             size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
             size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
-            slab_release(fs.base, fs.bytes);
+            if (fs.base) slab_release(fs.base, fs.bytes);
+            if (fs.borrow) { fs.borrow = false; fs.ext_pix = nullptr; fs.ext_next = nullptr; S->borrowers--; }   /* gets a slab of its own */
             fs.base = nullptr; fs.staged = false;
             fs.P = (int) (np > cap ? cap : np);
             fs.PA = (int) (npa > cap ? cap : npa);

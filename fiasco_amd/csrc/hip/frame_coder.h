@@ -131,7 +131,14 @@ typedef struct DevFrame {
     /* ---- optional per-call trace (FIASCO_AMD_TRACE), compared with the oracle's ---- */
     struct FcTrace *trace;
     int      trace_cap, trace_n;
+    /* ---- frame queue (core_hip.cpp): the slab the pointers above were computed for.  A launch
+     * with more frames than slabs runs one workgroup per SLAB; each takes frames off a queue and
+     * re-bases the slab pointers of the frame's descriptor onto its own slab. ---- */
+    char    *slab_base;
+    unsigned long long slab_bytes;
 } DevFrame;
+
+#define FC_DESC_WORDS ((sizeof(DevFrame) + 7) / 8)      /* 8-byte words of a descriptor */
 
 /* automaton row of one state, as store_state_data keeps it */
 typedef struct FcSavedRow {

@@ -2236,11 +2236,56 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
     sh.states = nb;
 }
 
-__global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
+/*
+ *  One workgroup per frame.  A launch may hold more frames than slabs (more than the chip runs at
+ *  once, or than HBM holds): the first `nlend` frames own a slab each, the others borrow one --
+ *  the hardware's workgroup dispatcher is the queue.  A workgroup that finishes hands its slab to
+ *  a ring of free slabs (ring[ctr[1]++] = base); a borrower takes the next ticket (ctr[0]++) and
+ *  waits for that entry.  With as many slabs as resident workgroups the entry is always there
+ *  already: the borrower only became resident because another workgroup had left.  The borrower
+ *  re-bases every slab pointer of its own descriptor (ptrmask: one bit per 8-byte word) onto the
+ *  slab it got.  No tail of idle CUs waiting for the slowest of the first frames, no limit on the
+ *  size of a launch from the 200 MB slabs.
+ */
+__global__ void __launch_bounds__(B, FC_WG_PER_CU)
+FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask)
 {
     __shared__ Sh sh;
     DevFrame &F = frames[blockIdx.x];
     const int tid = threadIdx.x;
+
+    if (ring && blockIdx.x >= nlend) {
+        /* a frame without a slab: wait for the next free one and move the descriptor onto it */
+        __shared__ unsigned long long got;
+        if (tid == 0) {
+            const unsigned t = atomicAdd(&ctr[0], 1u);
+            unsigned long long b;
+            while ((b = __hip_atomic_load(&ring[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+                __builtin_amdgcn_s_sleep(32);
+            got = b;                                        /* (the acquire has dropped the CU's L1: nothing stale of the slab's earlier users) */
+        }
+        __syncthreads();
+        {
+            unsigned long long *d = (unsigned long long *) &F;
+            const unsigned long long lo = (unsigned long long) F.slab_base, span = F.slab_bytes;
+            const unsigned long long delta = got - lo;
+            unsigned long long v[(FC_DESC_WORDS + B - 1) / B];
+#pragma unroll
+            for (unsigned k = 0; k < (FC_DESC_WORDS + B - 1) / B; k++) {      /* read everything first: slab_base moves too */
+                const unsigned w = k * B + tid;
+                v[k] = w < FC_DESC_WORDS ? d[w] : 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned k = 0; k < (FC_DESC_WORDS + B - 1) / B; k++) {
+                const unsigned w = k * B + tid;
+                if (w < FC_DESC_WORDS && ((ptrmask[w >> 5] >> (w & 31)) & 1u) && v[k] - lo < span) d[w] = v[k] + delta;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();                    /* the descriptor is read through the scalar cache */
+    }
 
     if (tid < 10 && tid >= 1)
         sh.m0tab[tid] = (float) -log2((double) (1 - 1 / (float) (1 << tid)));
@@ -2461,9 +2506,18 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU) FC_KERNEL(DevFrame *frames)
         const unsigned n16 = F.pack_bytes / 16;
         for (unsigned i = tid; i < n16; i += B) dst[i] = src[i];
     }
+    if (ring) {                               /* the slab is free for the next frame without one */
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned i = atomicAdd(&ctr[1], 1u);
+            __hip_atomic_store(&ring[i], (unsigned long long) F.slab_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
-extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, hipStream_t stream)
+extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                          const unsigned *ptrmask, hipStream_t stream)
 {
-    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames);
+    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask);
 }

@@ -514,6 +514,7 @@ struct Staged {
     int       lender0 = -1;        /* first slot with a slab of the queue's layout */
     Layout    qL;                  /* that layout and capacity (the slot itself may be re-staged larger) */
     int       qP = 0, qPA = 0;
+    bool      qbig = false;        /* kernel build of the queue's frames */
     size_t    lenders = 0, borrowers = 0, lender_cap = 0;
     char     *qpix = nullptr;      /* pixel planes of the borrowers */
     size_t    qpix_bytes = 0, qpix_used = 0;
@@ -643,14 +644,15 @@ static void slot_layout(Staged *S, FrameSlot &fs)
 static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
-    return !fs.big && job->frame_type == FA_I_FRAME && !job->ycol_carry && !getenv("FIASCO_AMD_NO_QUEUE");
+    /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !getenv("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
 static bool queue_layout(const Staged *S, const FrameSlot &fs)
 {
     if (S->lender0 < 0) return false;
-    return fs.P == S->qP && fs.PA == S->qPA && memcmp(&fs.L, &S->qL, sizeof(Layout)) == 0;
+    return fs.P == S->qP && fs.PA == S->qPA && fs.big == S->qbig && memcmp(&fs.L, &S->qL, sizeof(Layout)) == 0;
 }
 
 static void fill_frame(FrameSlot &fs, const fa_job *job);
@@ -856,10 +858,10 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         if (stage_slot(S, fs)) {
             if (elig && S->lender0 < 0) {
                 S->lender0 = (int) k; S->lenders = 1;
-                S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA;
+                S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (512-thread build for P > 3072: one per CU) */
-                S->lender_cap = (size_t) cus * (fs.P > 12 * 256 ? 1 : 4);
+                S->lender_cap = (size_t) cus * (fs.big ? (fs.P > 12 * 256 ? 1 : 2) : (fs.P > 12 * 256 ? 1 : 4));
                 if (getenv("FIASCO_AMD_QUEUE_SLABS") && atoi(getenv("FIASCO_AMD_QUEUE_SLABS")) > 0)
                     S->lender_cap = (size_t) atoi(getenv("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
             } else if (elig && queue_layout(S, fs)) S->lenders++;

@@ -848,6 +848,44 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
+    if (!S->slots.empty() && !getenv("FIASCO_AMD_NO_TIGHT")) {
+        /* HBM-bound batches (4K: a slab is 3 GB, 97 % of it the Gram tables, quadratic in the state
+         * capacity): when the slabs the chip could keep busy do not fit, the capacity guess drops
+         * from 1.375 to 1.15 states per block of the largest block level -- a third more frames in
+         * flight; a frame that outgrows it is encoded again with 1.5 x the capacity (complete_wave) */
+        FrameSlot probe = S->slots[0];
+        slot_layout(S, probe);
+        size_t free_b = 0, total_b = 0, pooled = 0;
+        for (size_t i = 0; i < g_free.size(); i++) pooled += g_free[i].bytes;
+        size_t want = S->slots.size();
+        const size_t resident = (size_t) cus * (probe.big ? 2 : 4);
+        if (want > resident) want = resident;
+        const bool hbm_bound = hipMemGetInfo(&free_b, &total_b) == hipSuccess && probe.L.total * want > free_b + pooled;
+        if ((hbm_bound || S->slots.size() > resident) && queue_eligible(S, probe)) {
+            /* the pixel planes of the frames that will queue for a slab: set aside before the slabs
+             * take what HBM has (when HBM is the limit nobody knows yet how many slabs will fit) */
+            const fa_image *im = jobs[probe.job].image;
+            const size_t need = align_up((size_t) im->width * im->height * (im->color ? 3 : 1) * 2, 256);
+            const size_t frames = hbm_bound ? S->slots.size() : S->slots.size() - resident;
+            if (hipMalloc((void **) &S->qpix, need * frames) == hipSuccess) { S->qpix_bytes = need * frames; S->qpix_used = 0; }
+            else { S->qpix = nullptr; (void) hipGetLastError(); }
+        }
+        if (hbm_bound)
+            for (size_t k = 0; k < S->slots.size(); k++) {
+                FrameSlot &fs = S->slots[k];
+                const fa_job *job = &jobs[fs.job];
+                const fa_cparams *cp = &job->cp;
+                unsigned bw = fa_width_of_level(cp->lc_max_level), bh = fa_height_of_level(cp->lc_max_level);
+                size_t blocks = (size_t) ((job->image->width + bw - 1) / bw) * ((job->image->height + bh - 1) / bh);
+                size_t tight = align_up(blocks + blocks * 3 / 20 + 64, 64);
+                if (tight > cp->limit_states) tight = align_up(cp->limit_states, 64);
+                if ((size_t) fs.P <= tight) continue;
+                const size_t cap = align_up(cp->limit_states, 64);
+                fs.P = (int) tight;
+                fs.PA = job->image->color ? (int) (3 * tight > cap ? cap : 3 * tight) : fs.P;
+                if (fs.PA < fs.P) fs.PA = fs.P;
+            }
+    }
     for (size_t k = 0; k < S->slots.size(); k++) {
         FrameSlot &fs = S->slots[k];
         const bool elig = queue_eligible(S, fs);

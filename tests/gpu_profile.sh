@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the same command  -> gpurun_out/prof/kernel_trace_stats.txt
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC / SQ, separate passes, no tracing flags
 #      (MI355X_MICROARCH.md, HBM section)                    -> gpurun_out/prof/pmc_*.txt
-#   4. the 4K workload (192 frames of 3840x2160, limits extension): bench line only -- rocprofv3
+#   4. the 4K workload (256 frames of 3840x2160, limits extension): bench line only -- rocprofv3
 #      --kernel-trace around the 4K run did not return on this pool (round 2: killed after 39 min),
 #      so bench.py's own HIP-event launch time is the 4K kernel figure
 # Summaries are produced with profiles/summarize_rocpd.py and copied into profiles/ by hand
@@ -27,7 +27,7 @@ timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/pmc_tcc -
 python3 $R/profiles/summarize_rocpd.py $O/pmc_tcc/*_results.db > $O/pmc_tcc.txt 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop > $O/bench_pmc_sq.json 2> $O/pmc_sq.err
 python3 $R/profiles/summarize_rocpd.py $O/pmc_sq/*_results.db > $O/pmc_sq.txt 2>&1
-# 4K: 192 frames in one launch through the frame queue (HBM holds about 90 of the 3.1 GB slabs)
-timeout 900 python3 $R/bench.py --width 3840 --height 2160 --frames-per-gpu 192 --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop > $O/bench_4k.json 2> $O/bench_4k.err
+# 4K: 256 frames in one launch through the frame queue (HBM holds about 130 of the 2.2 GB slabs of the tight capacity guess)
+timeout 900 python3 $R/bench.py --width 3840 --height 2160 --frames-per-gpu 256 --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop > $O/bench_4k.json 2> $O/bench_4k.err
 rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc $O/pmc_sq   # keep the summaries only
 grep -h fiasco $O/kernel_trace_stats.txt $O/pmc_*.txt | head -40

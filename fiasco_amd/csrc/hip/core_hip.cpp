@@ -24,13 +24,13 @@
 #include "libfiasco_amd_hip.h"
 
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
@@ -470,7 +470,14 @@ struct FrameSlot {
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
     const int16_t *ext_next = nullptr;   /* ... of the frames the NEXT pass encodes */
+    /* the host image this pass encodes, as of its submit: fiasco_amd_batch_upload() may point
+     * job->image at the NEXT pass's frames while this one is still running, and a re-stage of the
+     * running pass (capacity regrow, later wave) must not read those */
+    const fa_image *src = nullptr;
 };
+
+struct Staged;
+static inline const fa_image *slot_image(const Staged *S, const FrameSlot &fs);
 
 struct Staged {
     unsigned n = 0;
@@ -524,6 +531,11 @@ struct Staged {
     unsigned *d_ptrmask = nullptr;
     bool      ptrmask_ready = false;
 };
+
+static inline const fa_image *slot_image(const Staged *S, const FrameSlot &fs)
+{
+    return fs.src ? fs.src : S->jobs[fs.job].image;
+}
 
 static void fill_frame(FrameSlot &fs, const fa_job *job)
 {
@@ -679,7 +691,7 @@ static int stage_borrower(Staged *S, FrameSlot &fs, size_t frames_left)
     fs.ext_pix = (const int16_t *) (S->qpix + S->qpix_used);
     fs.F.pix16 = fs.ext_pix;
     for (int b = 0; b < bands; b++)
-        if (hipMemcpyAsync(S->qpix + S->qpix_used + (size_t) b * npix * 2, job->image->pixels[b], npix * 2,
+        if (hipMemcpyAsync(S->qpix + S->qpix_used + (size_t) b * npix * 2, slot_image(S, fs)->pixels[b], npix * 2,
                            hipMemcpyHostToDevice, S->stream) != hipSuccess) {
             snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
             fs.borrow = false; fs.ext_pix = nullptr;
@@ -732,7 +744,7 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     }
     if (fs.ext_pix) fs.F.pix16 = fs.ext_pix;       /* the planes live outside the slab already */
     for (int b = 0; b < bands && !fs.ext_pix; b++)
-        if (hipMemcpyAsync(fs.base + fs.L.pix16 + (size_t) b * npix * 2, job->image->pixels[b], npix * 2,
+        if (hipMemcpyAsync(fs.base + fs.L.pix16 + (size_t) b * npix * 2, slot_image(S, fs)->pixels[b], npix * 2,
                            hipMemcpyHostToDevice, S->stream) != hipSuccess) {
             snprintf(job->errmsg, sizeof job->errmsg, "HIP error: pixel upload failed");
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
@@ -826,6 +838,10 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         unsigned bw = fa_width_of_level(cp->lc_max_level), bh = fa_height_of_level(cp->lc_max_level);
         size_t blocks = (size_t) ((jobs[i].image->width + bw - 1) / bw) * ((jobs[i].image->height + bh - 1) / bh);
         size_t guess = blocks + blocks * 3 / 8 + 64;
+        /* tests / experiments: FIASCO_AMD_CAP_GUESS=<states> forces the first guess (a frame that
+         * outgrows it is encoded again with 1.5 x the capacity, complete_wave) */
+        if (getenv("FIASCO_AMD_CAP_GUESS") && atoi(getenv("FIASCO_AMD_CAP_GUESS")) > 0)
+            guess = (size_t) atoi(getenv("FIASCO_AMD_CAP_GUESS"));
         if (guess > cp->limit_states) guess = cp->limit_states;
         FrameSlot fs;
         fs.job = (int) i;
@@ -1215,7 +1231,11 @@ static bool launch_wave(Staged *S)
     /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
     fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
     {
-        typedef void (*launch_fn)(DevFrame *, unsigned, unsigned, unsigned long long *, unsigned *, const unsigned *, hipStream_t);
+        typedef void (*launch_fn)(DevFrame *, unsigned, unsigned, unsigned long long *, unsigned *, const unsigned *,
+                                  unsigned long long, hipStream_t);
+        /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
+        unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
+        if (getenv("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(getenv("FIASCO_AMD_QUEUE_WAIT_MS"));
         static const launch_fn launch[4] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide };
         size_t first = 0;
         for (int g = 0; g < 4 && !fail; g++) {
@@ -1228,17 +1248,17 @@ static bool launch_wave(Staged *S)
                     fail = fail || hipMemcpyAsync(S->d_frames + at, hf.data() + at, sizeof(DevFrame) * nq,
                                                   hipMemcpyHostToDevice, S->stream) != hipSuccess;
                     if (group_lend[g])
-                        launch[g](S->d_frames + at, (unsigned) group_lend[g], (unsigned) group_lend[g], nullptr, nullptr, nullptr, S->stream);
+                        launch[g](S->d_frames + at, (unsigned) group_lend[g], (unsigned) group_lend[g], nullptr, nullptr, nullptr, qwait, S->stream);
                 } else {
                     unsigned long long *ring = S->d_ring + (size_t) g * batch.size();
                     fail = fail || hipMemsetAsync(S->d_queue + 2 * g, 0, 2 * sizeof(unsigned), S->stream) != hipSuccess;
                     fail = fail || hipMemsetAsync(ring, 0, nq * sizeof(unsigned long long), S->stream) != hipSuccess;
                     launch[g](S->d_frames + at, (unsigned) nq, (unsigned) group_lend[g], ring, S->d_queue + 2 * g,
-                              S->d_ptrmask, S->stream);
+                              S->d_ptrmask, qwait, S->stream);
                 }
                 at += nq; plain -= nq;
             }
-            if (plain) launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, S->stream);
+            if (plain) launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, qwait, S->stream);
             first += group_n[g];
         }
     }
@@ -1339,11 +1359,21 @@ static void complete_wave(Staged *S)
             size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
             size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
             if (fs.base) slab_release(fs.base, fs.bytes);
-            if (fs.borrow) { fs.borrow = false; fs.ext_pix = nullptr; fs.ext_next = nullptr; S->borrowers--; }   /* gets a slab of its own */
+            /* a borrower gets a slab of its own; its pixel planes stay where they are (the queue's
+             * pixel buffer or an upload buffer): the host copy may belong to the next pass by now */
+            if (fs.borrow) { fs.borrow = false; S->borrowers--; }
             fs.base = nullptr; fs.staged = false;
             fs.P = (int) (np > cap ? cap : np);
             fs.PA = (int) (npa > cap ? cap : npa);
             if (fs.PA < fs.P) fs.PA = fs.P;
+            if (!stage_slot(S, fs)) fs.done = true;
+            continue;
+        }
+        if (st == FC_ERR_QUEUE && fs.borrow) {
+            /* the frame never got a slab from the queue (bounded wait in the kernel): a slab of its
+             * own in the next launch; its pixel planes stay where they are */
+            fs.borrow = false; S->borrowers--;
+            fs.base = nullptr; fs.staged = false;
             if (!stage_slot(S, fs)) fs.done = true;
             continue;
         }
@@ -1357,6 +1387,7 @@ static void complete_wave(Staged *S)
             const char *msg = "device coder failed";
             if (st == FC_ERR_STATES || st == FC_ERR_CAPACITY) msg = "Maximum number of states reached!";
             else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
+            else if (st == FC_ERR_QUEUE) msg = "device coder: frame queue gave no slab";
             else if (st == FC_ERR_INTERNAL) msg = "device coder: frame exceeds a built-in capacity (recursion depth, snapshot stack or 16384 states)";
             snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
         }
@@ -1379,7 +1410,10 @@ extern "C" int fa_core_submit(void *h)
     if (!S || !S->ok) return 0;
     if (S->inflight) return 1;
     /* job status / automata of the previous pass stay readable until fa_core_finish() */
-    for (size_t k = 0; k < S->slots.size(); k++) S->slots[k].done = false;
+    for (size_t k = 0; k < S->slots.size(); k++) {
+        S->slots[k].done = false;
+        S->slots[k].src = S->jobs[S->slots[k].job].image;      /* see FrameSlot::src */
+    }
     S->good = 0; S->broken = false;
     if (S->up_pending) {
         /* a new pass takes over the replacement inputs: the launch waits for their transfer,

@@ -35,7 +35,9 @@
 #define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
 #define FC_MAXBASIS 16          /* states of the initial basis */
 
-enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5 };
+enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5,
+       FC_ERR_QUEUE = 6 };    /* frame queue: no free slab arrived in time, encode again with a slab of its own */
+#define FC_QUEUE_WAIT_TICKS 60000000000ull      /* default bound of that wait: 10 minutes of the 100 MHz wall clock */
 
 struct FcTrace;
 typedef struct DevFrame {

@@ -2248,7 +2248,8 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
  *  size of a launch from the 200 MB slabs.
  */
 __global__ void __launch_bounds__(B, FC_WG_PER_CU)
-FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask)
+FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask,
+          unsigned long long queue_wait_ticks)
 {
     __shared__ Sh sh;
     DevFrame &F = frames[blockIdx.x];
@@ -2260,11 +2261,23 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         if (tid == 0) {
             const unsigned t = atomicAdd(&ctr[0], 1u);
             unsigned long long b;
-            while ((b = __hip_atomic_load(&ring[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+            /* Forward progress rests on an observation, not a promise of HIP: workgroups become
+             * resident in blockIdx order, so every slab owner is resident (or done) before a
+             * borrower spins here.  Should that ever not hold the wait is bounded (wall clock,
+             * 100 MHz): the frame gives up with FC_ERR_QUEUE and the host encodes it again in a slab
+             * of its own (complete_wave) -- a diagnostic and a retry instead of a hung GPU. */
+            const unsigned long long t_give_up = wall_clock64() + queue_wait_ticks;
+            while ((b = __hip_atomic_load(&ring[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (wall_clock64() > t_give_up) break;
                 __builtin_amdgcn_s_sleep(32);
+            }
             got = b;                                        /* (the acquire has dropped the CU's L1: nothing stale of the slab's earlier users) */
         }
         __syncthreads();
+        if (got == 0) {                                     /* uniform: no slab arrived */
+            if (tid == 0) { F.status = FC_ERR_QUEUE; F.states = 0; }
+            return;
+        }
         {
             unsigned long long *d = (unsigned long long *) &F;
             const unsigned long long lo = (unsigned long long) F.slab_base, span = F.slab_bytes;
@@ -2517,7 +2530,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 }
 
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                          const unsigned *ptrmask, hipStream_t stream)
+                          const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask);
+    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask, queue_wait_ticks);
 }

@@ -245,7 +245,14 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             jobs[nb].cp.lc_min_level = q->carry;
             jobs[nb].frame_type = type; jobs[nb].past = q->past; jobs[nb].future = q->future;
             jobs[nb].wfa = fa_wfa_alloc(s->cp.limit_states);
-            if (!jobs[nb].wfa) { fa_set_error("Out of memory!"); goto out; }
+            if (!jobs[nb].wfa) {
+                /* give back what this step has prepared so far (the `out' path only knows run[]) */
+                unsigned j;
+                fa_set_error("Out of memory!");
+                fa_image_free(ims[nb]);
+                for (j = 0; j < nb; j++) { fa_wfa_free(jobs[j].wfa); fa_image_free(ims[j]); }
+                goto out;
+            }
             if (!fa_load_basis(s->op->basis_name, jobs[nb].wfa) || jobs[nb].wfa->states >= s->cp.limit_states) {
                 if (jobs[nb].wfa->states >= s->cp.limit_states) fa_set_error("Maximum number of states reached!");
                 snprintf(s->gerr[q->g], 160, "%s", fiasco_get_error_message());
@@ -428,8 +435,12 @@ int fiasco_amd_seq_search(fiasco_amd_seq_t *q, const unsigned *carry_in, const u
 int fiasco_amd_seq_gop_result(const fiasco_amd_seq_t *q, unsigned gop, unsigned *carry_out, int *failed)
 {
     if (gop >= q->s->ngop || !q->s->gdone[gop]) return 0;
-    fa_seq_gop_result(q->s, gop, carry_out, failed);
-    if (*failed) fa_set_error("%s", q->s->gerr[gop]);
+    {
+        int f = 0;
+        fa_seq_gop_result(q->s, gop, carry_out, &f);
+        if (failed) *failed = f;
+        if (f) fa_set_error("%s", q->s->gerr[gop]);
+    }
     return 1;
 }
 const unsigned char *fiasco_amd_seq_ycol(const fiasco_amd_seq_t *q, unsigned frame)

@@ -494,14 +494,16 @@ static void locate_delta_images(fa_wfa *wfa)
 
 /* encode_nd_tree :65-177: breadth first, one binary decision per child between p_min_level and
  * p_max_level ("the child's range is predicted": the (state,label) carries edges as well);
- * adaptive binary coder, counts halved above 50.  Returns the number of predicted ranges. */
-static unsigned write_nd_tree(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out)
+ * adaptive binary coder, counts halved above 50.  Stores the number of predicted ranges in *nused;
+ * returns 0 when the queue cannot be allocated (the reference aborts there). */
+static int write_nd_tree(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out, unsigned *nused)
 {
     unsigned *queue = (unsigned *) malloc(sizeof(unsigned) * (wfa->states + 1));
     unsigned head = 0, tail = 0, used = 0, label;
     unsigned sum0 = 1, sum1 = 11;
     ac16 a;
-    if (!queue) return 0;
+    *nused = 0;
+    if (!queue) { fa_set_error("Out of memory!"); return 0; }
     ac_init(&a, out);
     queue[tail++] = wfa->root_state;
     while (head < tail) {
@@ -536,15 +538,17 @@ static unsigned write_nd_tree(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out
     }
     ac_flush(&a);
     free(queue);
-    return used;
+    *nused = used;
+    return 1;
 }
 
 /* encode_nd_coefficients :179-242: the weights of every edge on a (state,label) that has a tree
  * child too, DC format, one adaptive context (scale 50) */
 static int write_nd(const fa_wfa *wfa, const fa_info *wi, fa_bitw *out)
 {
-    unsigned total = write_nd_tree(wfa, wi, out), n = 0, state, label, e;
+    unsigned total = 0, n = 0, state, label, e;
     unsigned *coeff, c_symbols = 1u << (wi->dc_rpf.mantissa_bits + 1);
+    if (!write_nd_tree(wfa, wi, out, &total)) return 0;
     if (!total) return 1;
     coeff = (unsigned *) calloc(total, sizeof(unsigned));
     if (!coeff) { fa_set_error("Out of memory!"); return 0; }

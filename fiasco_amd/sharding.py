@@ -60,23 +60,42 @@ def encode_sequence(lib, pnm_list, quality=20.0, options=None, device="cpu", gro
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     seq = fiasco_amd.Sequence(lib, pnm_list, quality, options, rank, world)
+    # An error on ONE rank (out of HBM, a HIP error on its GPU ...) must not leave the others
+    # blocked in the next collective: local errors are caught, folded into the tensor that is
+    # reduced anyway (one extra row / element), and every rank raises together after the reduce.
+    local_err = None
+
+    def _raise_together(flag_sum, what):
+        if flag_sum:
+            raise fiasco_amd.FiascoError(local_err or "%s failed on another rank" % what)
+
     try:
         G, K = seq.gops, seq.frames
         # every rank probes the first frame itself: the same guess everywhere, nothing to send
-        guess = seq.probe()
+        try:
+            guess = seq.probe()
+        except fiasco_amd.FiascoError as e:
+            local_err, guess = str(e), seq.initial_level
         carry = [seq.initial_level] + [guess] * (G - 1)
         todo = [True] * G
         used, left, failed = [0] * G, [0] * G, [False] * G
         for _ in range(64):
-            seq.search(carry, todo)
-            mine = torch.zeros((G, 3), dtype=torch.int64, device=device)
-            for g in range(G):
-                if g % world == rank and todo[g]:
-                    out, bad, _msg = seq.gop_result(g)
-                    mine[g] = torch.tensor([carry[g], out, 1 if bad else 0], dtype=torch.int64, device=device)
+            mine = torch.zeros((G + 1, 3), dtype=torch.int64, device=device)
+            if local_err is None:
+                try:
+                    seq.search(carry, todo)
+                    for g in range(G):
+                        if g % world == rank and todo[g]:
+                            out, bad, _msg = seq.gop_result(g)
+                            mine[g] = torch.tensor([carry[g], out, 1 if bad else 0], dtype=torch.int64, device=device)
+                except fiasco_amd.FiascoError as e:
+                    local_err = str(e)
+            if local_err is not None:
+                mine[G, 0] = 1
             if world > 1:
                 dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=group)
             got = mine.cpu().tolist()
+            _raise_together(got[G][0], "the search of a group of pictures")
             for g in range(G):
                 if todo[g]:
                     used[g], left[g], failed[g] = got[g][0], got[g][1], bool(got[g][2])
@@ -109,18 +128,28 @@ def encode_sequence(lib, pnm_list, quality=20.0, options=None, device="cpu", gro
                 chain = torch.where(raw[k] != 2, raw[k], chain)
                 if seq.gop_of(k) % world == rank:
                     resolved[k] = bytes(chain.numpy().tobytes())
-        local = {k: seq.write(k, resolved.get(k)) for k in range(K) if seq.gop_of(k) % world == rank}
+        local = {}
+        try:
+            local = {k: seq.write(k, resolved.get(k)) for k in range(K) if seq.gop_of(k) % world == rank}
+        except fiasco_amd.FiascoError as e:
+            local_err = str(e)
     finally:
         seq.free()
     if world == 1:
+        _raise_together(local_err is not None, "the stream writer")
         return b"".join(local[k] for k in range(K))
     # gather_streams expects item i on rank i % world: the frames are owned by GOP, so gather in
-    # two steps -- lengths, then the payloads padded to the longest
-    lengths = torch.zeros(K, dtype=torch.int64, device=device)
-    for k, b in local.items():
-        lengths[k] = len(b)
+    # two steps -- lengths (+ one element for "a rank failed"), then the payloads padded to the longest
+    lengths = torch.zeros(K + 1, dtype=torch.int64, device=device)
+    if local_err is not None:
+        lengths[K] = 1
+    else:
+        for k, b in local.items():
+            lengths[k] = len(b)
     dist.all_reduce(lengths, op=dist.ReduceOp.SUM, group=group)
     lens = lengths.cpu().tolist()
+    _raise_together(lens[K], "the stream writer")
+    lens = lens[:K]
     buf = torch.zeros((K, max(lens) if K else 1), dtype=torch.uint8, device=device)
     for k, b in local.items():
         buf[k, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)

@@ -120,3 +120,39 @@ def test_two_rank_gop_sharding_with_speculation(oracle, manifest, inputs, tmp_pa
         import hashlib
         assert hashlib.md5(want).hexdigest() == case["md5"]        # the real reference's stream
     mp.spawn(_seq_worker, args=(2, 29533, paths, pattern or "i", pred, want, ORACLE_LIB), nprocs=2, join=True)
+
+
+def _seq_fail_worker(rank, world, port, paths, oracle_lib, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import fiasco_amd
+    from fiasco_amd.sharding import encode_sequence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = fiasco_amd.Library(oracle_lib)
+    lib.set_verbosity(0)
+    if rank == 1:                      # this rank's device "fails" in its first sweep
+        def boom(self, carry_in, todo):
+            raise fiasco_amd.FiascoError("out of HBM (simulated)")
+        fiasco_amd.Sequence.search = boom
+    o = lib.cli_options(pattern="i")
+    try:
+        encode_sequence(lib, [open(p, "rb").read() for p in paths], 20.0, o, device="cpu")
+        q.put((rank, "no error"))
+    except fiasco_amd.FiascoError as e:
+        q.put((rank, str(e)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_an_error_on_one_rank_raises_on_all_ranks(inputs):
+    """A rank whose search fails must not leave the others blocked in the next all-reduce: the
+    error is folded into the reduced tensor and every rank raises (fiasco_amd/sharding.py)."""
+    from conftest import ORACLE_LIB
+    paths = [inputs.path(n) for n in ("c256", "c256b")]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_seq_fail_worker, args=(2, 29537, paths, ORACLE_LIB, q), nprocs=2, join=True)
+    got = dict(q.get() for _ in range(2))
+    assert "simulated" in got[1] and "another rank" in got[0], got

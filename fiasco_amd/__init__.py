@@ -59,7 +59,9 @@ class Stats(ctypes.Structure):
                 ("t_append", ctypes.c_ulonglong), ("t_serial", ctypes.c_ulonglong),
                 ("t_total", ctypes.c_ulonglong), ("t_mpA", ctypes.c_ulonglong),
                 ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong),
-                ("dbg", ctypes.c_ulonglong * 8)]
+                ("dbg", ctypes.c_ulonglong * 8), ("states_sum", ctypes.c_ulonglong),
+                ("states_max", ctypes.c_ulonglong), ("reencodes", ctypes.c_ulonglong),
+                ("frames_by_build", ctypes.c_ulonglong * 4)]
 
 
 def build(verbose=False):

@@ -49,10 +49,24 @@ static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
     return cp->lc_min_level <= cp->images_level || cp->lc_max_level > 10 || cp->max_elements > 3
            || cp->second_domain_block || cp->check_for_underflow || cp->check_for_overflow || cp->full_search
            || (cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF
-           /* per-depth aac snapshots beyond the default build's LDS pool (840 x 16 bytes,
-            * frame_coder.hip SNAP_POOL16): the big build parks them in HBM */
-           || (cp->level - cp->lc_min_level + 3) * 2
-              * ((32 + 2 * ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs) + 15) / 16) > 840;
+           /* aac snapshots beyond the default build's LDS pool (frame_coder.hip SNAP_POOL16; one per
+            * depth + one per block level with children): the big build parks them in HBM */
+           || (cp->level - cp->lc_min_level + 3 + cp->lc_max_level - cp->lc_min_level)
+              * ((32 + 2 * ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs) + 15) / 16) > FC_SNAP16_WIDE;
+}
+
+/* The 256-thread default build keeps a shorter stack and smaller snapshot pools in LDS than the
+ * 512-thread one (frame_coder.hip: FC_MAXDEPTH_NARROW, FC_SNAP16_NARROW, FC_SNAPTM_NARROW -- sized
+ * for what the stock reference accepts, level <= 22); a frame beyond them is given to the
+ * 512-thread build whatever the size of the launch. */
+static bool needs_wide_variant(const fa_cparams *cp)
+{
+    unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
+    const unsigned n16 = (32 + 2 * ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs) + 15) / 16;
+    const unsigned depths = cp->level - cp->lc_min_level + 3;
+    return depths - 1 > FC_MAXDEPTH_NARROW
+           || (depths + cp->lc_max_level - cp->lc_min_level) * n16 > FC_SNAP16_NARROW
+           || depths * 4 * ((2 * cp->limit_level + 3) / 4) > FC_SNAPTM_NARROW;
 }
 
 static fiasco_amd_stats g_stats;
@@ -60,6 +74,23 @@ static fiasco_amd_stats g_stats;
 extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out) { *out = g_stats; }
 extern "C" void fiasco_amd_reset_stats(void) { memset(&g_stats, 0, sizeof g_stats); }
 extern "C" const char *fa_core_name(void) { return "hip-gfx950"; }
+
+/* workgroups (= frames) of a kernel build that one CU holds at once, as the runtime computes it
+ * from the build's registers and LDS (frame_coder.hip FC_OCCUPANCY) */
+extern "C" int fc_occupancy(void);
+extern "C" int fc_occupancy_wide(void);
+extern "C" int fc_occupancy_big(void);
+extern "C" int fc_occupancy_big_wide(void);
+static size_t frames_per_cu(bool big, bool wide)
+{
+    static int cache[4] = { 0, 0, 0, 0 };
+    const int i = (big ? 2 : 0) + (wide ? 1 : 0);
+    if (!cache[i]) {
+        cache[i] = i == 0 ? fc_occupancy() : i == 1 ? fc_occupancy_wide() : i == 2 ? fc_occupancy_big() : fc_occupancy_big_wide();
+        if (cache[i] < 1) cache[i] = 1;
+    }
+    return (size_t) cache[i];
+}
 
 /* one process per GPU: bind this process's coder to a device of the node */
 extern "C" void fiasco_amd_release_memory(void);
@@ -346,7 +377,7 @@ extern "C" void fiasco_amd_release_memory(void)
 /* ------------------------------------------------------------------ layout */
 
 struct Layout {
-    size_t gram, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
+    size_t gram, diag, ipis, cmax, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
@@ -366,6 +397,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(gram, (size_t) NL * P * P * 4);
     CARVE(diag, (size_t) NL * P * 4);
     CARVE(ipis, (size_t) NS * P * 4);
+    CARVE(cmax, (size_t) NS * (P / 64) * 4);        /* per heap slot and 64-state block (frame_coder.hip op_ipis) */
     CARVE(d5, (size_t) NA * P * 4);
     CARVE(d4, low ? (size_t) 2 * NA * P * 4 : 0);
     CARVE(img, (size_t) P * NI * 4);
@@ -466,6 +498,7 @@ struct FrameSlot {
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
+    bool     wide_only = false;  /* default geometry, but beyond the 256-thread build's LDS pools */
     bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
@@ -586,6 +619,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pix16 = (const int16_t *) (base + L.pix16);
     F.gram = (float *) (base + L.gram); F.diag = (float *) (base + L.diag);
     F.ipis = (float *) (base + L.ipis); F.d5 = (float *) (base + L.d5);
+    F.cmax = (float *) (base + L.cmax);
     F.d4 = (float *) (base + L.d4); F.imgT4 = (float *) (base + L.imgT4);
     F.img = (float *) (base + L.img); F.imgT = (float *) (base + L.imgT);
     F.norms = (float *) (base + L.norms);
@@ -847,6 +881,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
+        fs.wide_only = !fs.big && needs_wide_variant(cp);
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
@@ -874,7 +909,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         size_t free_b = 0, total_b = 0, pooled = 0;
         for (size_t i = 0; i < g_free.size(); i++) pooled += g_free[i].bytes;
         size_t want = S->slots.size();
-        const size_t resident = (size_t) cus * (probe.big ? 2 : 4);
+        const size_t resident = (size_t) cus * frames_per_cu(probe.big, probe.P > 12 * 256 || probe.wide_only);
         if (want > resident) want = resident;
         const bool hbm_bound = hipMemGetInfo(&free_b, &total_b) == hipSuccess && probe.L.total * want > free_b + pooled;
         if ((hbm_bound || S->slots.size() > resident) && queue_eligible(S, probe)) {
@@ -915,7 +950,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                 S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (512-thread build for P > 3072: one per CU) */
-                S->lender_cap = (size_t) cus * (fs.big ? (fs.P > 12 * 256 ? 1 : 2) : (fs.P > 12 * 256 ? 1 : 4));
+                S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only);
                 if (getenv("FIASCO_AMD_QUEUE_SLABS") && atoi(getenv("FIASCO_AMD_QUEUE_SLABS")) > 0)
                     S->lender_cap = (size_t) atoi(getenv("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
             } else if (elig && queue_layout(S, fs)) S->lenders++;
@@ -1112,6 +1147,8 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     g_stats.t_append += F.t_append; g_stats.t_serial += F.t_serial; g_stats.t_total += F.t_total;
     g_stats.t_mpA += F.t_mpA; g_stats.t_mpB += F.t_mpB; g_stats.n_blockevals += F.n_blockevals;
     for (int k = 0; k < 8; k++) g_stats.dbg[k] += F.dbg[k];
+    g_stats.states_sum += ns;
+    if (ns > g_stats.states_max) g_stats.states_max = ns;
     return 1;
 }
 
@@ -1178,13 +1215,14 @@ static bool launch_wave(Staged *S)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
-                    const bool wide = few || fs.P > 12 * 256;
+                    const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
                     if ((int) fs.big * 2 + (int) wide != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
                     ordered.push_back(batch[b]);
                     group_n[g]++;
+                    g_stats.frames_by_build[g]++;
                     if (part == 0) group_lend[g]++; else if (part == 1) group_borrow[g]++;
                 }
         batch.swap(ordered);
@@ -1356,6 +1394,7 @@ static void complete_wave(Staged *S)
         size_t cap = align_up(job->cp.limit_states, 64);
         if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
             /* capacity guess too small: bigger slab, same inputs, encode again */
+            g_stats.reencodes += 1;
             size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
             size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
             if (fs.base) slab_release(fs.base, fs.bytes);

@@ -12,6 +12,7 @@
  *    diag   [NL][P]    f32  Gram diagonal (matching-pursuit denominators)
  *    ipis   [NS][P]    f32  <range sub-block, state>, heap slot major
  *                           (reference ip_images_state, codec/cwfa.h:89, is state major)
+ *    cmax   [NS][P/64] f32  per slot and 64-state block: max of ipis^2 / diag (first-step bounds)
  *    d5     [NA][P]    f32  level-images_level dots of the current block, address major
  *    img    [P][NI]    f32  state images levels 0..images_level (reference layout)
  *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
@@ -29,6 +30,13 @@
 #define FC_BLOCK    256         /* threads per frame workgroup */
 #define FC_MAXDEPTH 22          /* recursion depth bound: level <= 26, lc_min >= 6 */
 #define FC_MAXDEPTH_BIG 32      /* big build: + the residual search of a predicted range */
+#define FC_MAXDEPTH_NARROW 18   /* 256-thread default build: level <= 22 with block levels from 6 */
+/* aac snapshot pool (16-byte units) of the default build, 256- and 512-thread variant */
+#define FC_SNAP16_NARROW 480    /* (19 depths + 4 block levels with children) x 20 uint4 = 460 at level 22, CLI models */
+#define FC_SNAP16_WIDE   840
+/* tree-model snapshots (words) of the default build: depths x 2 x MAXLEVEL, rounded to 16 bytes */
+#define FC_SNAPTM_NARROW 836    /* 19 depths x 11 uint4 (MAXLEVEL 22) */
+#define FC_SNAPTM_WIDE   1092   /* 21 depths x 13 uint4 */
 #define FC_MAXSAVE  512         /* states a prediction attempt can displace: 2^(12 - 4 + 1) */
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */
 #define FC_MAXCOEFF_BIG 640     /* big build: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
@@ -69,6 +77,9 @@ typedef struct DevFrame {
     /* ---- tables ---- */
     const int16_t *pix16;
     float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;
+    float   *cmax;         /* [NS][P / 64] largest <range, state>^2 / <state, state> of each 64-state block, per
+                            * heap slot of the current pixel block: the first step of a search starts its
+                            * ordered scan from these (mp_sl.inc) instead of sweeping the dictionary */
     float   *d4, *imgT4;   /* level images_level-1 twins of d5 / imgT (block levels down to 4) */
     float   *num, *den, *est, *ipdo;
     uint8_t *used;

@@ -69,9 +69,11 @@
 #if FC_VARIANT_WIDE
 #define FC_KERNEL    fiasco_frame_kernel_big_wide
 #define FC_LAUNCH    fc_launch_big_wide
+#define FC_OCCUPANCY fc_occupancy_big_wide
 #else
 #define FC_KERNEL    fiasco_frame_kernel_big
 #define FC_LAUNCH    fc_launch_big
+#define FC_OCCUPANCY fc_occupancy_big
 #endif
 #define FC_PIXELS    4096        /* 2^lc_max, lc_max <= 12 */
 #define FC_NIP       4           /* orthogonal vectors kept per candidate: max_elements - 1 */
@@ -80,9 +82,11 @@
 #if FC_VARIANT_WIDE
 #define FC_KERNEL    fiasco_frame_kernel_wide
 #define FC_LAUNCH    fc_launch_wide
+#define FC_OCCUPANCY fc_occupancy_wide
 #else
 #define FC_KERNEL    fiasco_frame_kernel
 #define FC_LAUNCH    fc_launch
+#define FC_OCCUPANCY fc_occupancy
 #endif
 #define FC_PIXELS    1024
 #define FC_NIP       2
@@ -91,6 +95,19 @@
  * i.e. at most 128 VGPRs and 40 KB of LDS per frame */
 #define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 4)
 #endif
+#endif
+/* FC_SCAN_SL: the matching-pursuit scan recomputes a candidate from its table rows in every pass
+ * (mp_sl.inc) instead of carrying it through the call in registers (mp_reg.inc) */
+#ifndef FC_SCAN_SL
+#define FC_SCAN_SL 0
+#endif
+/* FC_REG_MB: the register-resident scan replays its ordered rounds over up to one block per wave
+ * (mp_reg.inc) instead of one block per round */
+#ifndef FC_REG_MB
+#define FC_REG_MB 0
+#endif
+#ifndef FC_SL_NEXT_TOUCH
+#define FC_SL_NEXT_TOUCH 0
 #endif
 #define MAXED   FC_MAXED
 /* edges per label a state of this build can have (= max_elements the build accepts): the table
@@ -109,14 +126,19 @@ enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_R
 enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
 #if FC_VARIANT_BIG
 #define FC_DEPTH FC_MAXDEPTH_BIG
-#else
+#elif FC_VARIANT_WIDE
 #define FC_DEPTH FC_MAXDEPTH
+#else
+#define FC_DEPTH FC_MAXDEPTH_NARROW   /* deeper frames go to the 512-thread build (core_hip.cpp) */
 #endif
 
+/* edge slots of a range record: the vectors a build can keep plus the terminator (the stack of
+ * range records is a third of the default build's LDS) */
+#define RANGE_E (FC_MAXE + 1)
 struct Range {
     int   x, y, image, address, level, tree;
-    float weight[MAXED + 1];
-    short into[MAXED + 1];
+    float weight[RANGE_E];
+    short into[RANGE_E];
     float err, tree_bits, matrix_bits, weights_bits;
 #if FC_VARIANT_BIG
     float nd_tree_bits, nd_weights_bits, mv_tree_bits, mv_coord_bits;   /* codec/cwfa.h:68-73 */
@@ -177,11 +199,20 @@ struct __attribute__((aligned(16))) CoeffBuf {
     short cnt[FC_VARIANT_BIG ? FC_MAXCOEFF_BIG : FC_MAXCOEFF];
 };
 #if FC_VARIANT_BIG
-#define SNAP_POOL16 1200           /* uint4 slots for aac snapshots: depth x 2 x n16 */
+#define SNAP_POOL16 880            /* uint4 slots for aac snapshots: depth x 2 x n16 (what outgrows it lives in HBM) */
 #define SNAP_TM_WORDS 2392         /* tree-model snapshots: depth x 4 x MAXLEVEL words */
 #else
-#define SNAP_POOL16 840
-#define SNAP_TM_WORDS 2184
+/* aac snapshots of the default build: one slot per depth (the models at the entry of the node) and
+ * one more for each block level that has both a linear combination and children (the models
+ * after the combination): (depths + levels) x n16 uint4.  The 256-thread build is sized for the
+ * frames the stock reference accepts (level <= 22) at the CLI's models; what needs more goes to
+ * the 512-thread build (one frame per CU, LDS to spare) -- core_hip.cpp routes by these numbers. */
+#ifndef SNAP_POOL16
+#define SNAP_POOL16 (FC_VARIANT_WIDE ? FC_SNAP16_WIDE : FC_SNAP16_NARROW)
+#endif
+/* the default build never prices with the second tree model (prediction, big build only): a
+ * snapshot holds the first one alone, 2 x MAXLEVEL words rounded to 16 bytes (21 depths x 13 uint4) */
+#define SNAP_TM_WORDS (FC_VARIANT_WIDE ? FC_SNAPTM_WIDE : FC_SNAPTM_NARROW)
 #endif
 #if FC_VARIANT_BIG || FC_VARIANT_WIDE
 #define NBLOCKMIN   256            /* 64-candidate blocks: D <= 16384 */
@@ -243,6 +274,10 @@ struct Sh {
     int      apx_stage, apx_it, apx_more;   /* retry plan of approximate_range (lane 0) */
 #endif
     float    blockmin[NBLOCKMIN];
+#if FC_SCAN_SL || FC_REG_MB
+    /* mp_sl.inc / mp_reg.inc: (estimate, costs) of the candidates of the blocks of a round, per round parity */
+    float    slx[2][2][B / 64][64];
+#endif
     float    pixels[FC_PIXELS];
     float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
     unsigned long long tk[12];     /* ticks per op (lane 0) */
@@ -276,6 +311,7 @@ struct Sh {
         float *d5, *d4;            /* big build: the active level-5 / level-4 dot tables */
         const unsigned *l2_keys; const double *l2_vals; unsigned l2_mask;
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
+        int snap_b1;               /* default build: first "after the linear combination" snapshot slot minus its depth */
         float rpf_range, dc_range;
     } par;
     int      states;               /* wfa->states */
@@ -541,9 +577,64 @@ __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRow
     }
 }
 
+/* maximum over the 64 lanes of a wave on the DPP path, result in LANE 63 (see wave_min_l63 in
+ * mp_device.inc); the values here are >= 0 */
+__device__ __forceinline__ float wave_max_l63(float v)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+
+/* four independent maxima at once: the four DPP chains are interleaved, so the two wait states
+ * between a VALU write and a DPP read of the same register are filled with the other chains */
+__device__ __forceinline__ void wave_max4_l63(float &a, float &b, float &c, float &d)
+{
+#define MAX4_STEP(ctl)                                                     \
+        "v_max_f32_dpp %0, %0, %0 " ctl "\n\t"                             \
+        "v_max_f32_dpp %1, %1, %1 " ctl "\n\t"                             \
+        "v_max_f32_dpp %2, %2, %2 " ctl "\n\t"                             \
+        "v_max_f32_dpp %3, %3, %3 " ctl "\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        MAX4_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        MAX4_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        MAX4_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        MAX4_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        MAX4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        MAX4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef MAX4_STEP
+}
+
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
- * onto zero, which is the reference's accumulation order onto its zeroed slots. */
+ * onto zero, which is the reference's accumulation order onto its zeroed slots.
+ *
+ * Default build, luminance: the same pass leaves in F.cmax, per slot and 64-state block, the
+ * largest num^2 / den a candidate of the block can bring to the FIRST step of a search of that
+ * sub-block (num = the entry just computed, den = the Gram diagonal of the slot's level; 0 for a
+ * state that cannot be a candidate).  The stage-1 estimate of a candidate falls with that
+ * quotient and rises with its rate terms, every rounding step is monotone: (smallest rate
+ * terms) x price + error - cmax is a lower bound of every estimate in the block, and a lower
+ * bound is all the ordered scan needs to decide which blocks it may skip -- the first step of a
+ * call does not sweep the dictionary at all (mp_sl.inc).  Blocks are recomputed whole: `from` is
+ * rounded down to a block boundary (the lanes are there anyway; the entries of the older states
+ * come out as they are). */
 __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level;
@@ -552,6 +643,16 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
     level = __builtin_amdgcn_readfirstlane(level); from = __builtin_amdgcn_readfirstlane(from);
     GLOBAL_AS float *const ipis = uniform_ptr(ACT_IPIS(F, sh));
     GLOBAL_AS const float *const d5 = uniform_ptr((const float *) ACT_D5(F, sh));
+#if FC_SCAN_SL && !FC_VARIANT_BIG
+    const bool bounds = !sh.band;                      /* uniform */
+    GLOBAL_AS float *const cmax = uniform_ptr(F.cmax);
+    GLOBAL_AS const float *const diag = uniform_ptr((const float *) F.diag);
+    GLOBAL_AS const int16_t *const pos = uniform_ptr((const int16_t *) F.pos);
+    const int NB = P >> 6, lane = tid & 63;
+    if (bounds) from &= ~63;
+#else
+    const bool bounds = false;
+#endif
     AutoTabs T;
     auto_tabs(F, T);
     for (int lv = il + 1; lv <= level; lv++) {
@@ -561,15 +662,24 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
         int adr0 = address << delta;
         GLOBAL_AS const float *src0 = (lv == il + 1) ? d5 + (size_t) (adr0 * 2) * P
                                                      : ipis + (size_t) (slot0 * 2 + 1) * P;
+#if FC_SCAN_SL && !FC_VARIANT_BIG
+        const float rsize = 1.0f / (float) (1u << lv);
+        const unsigned qrow = (unsigned) ((lv - F.gl0) * P);
+#endif
         /* the rows of the NEXT state of this lane are requested before the gathers of the
-         * current one are waited for (one memory round trip per state instead of two) */
+         * current one are waited for (one memory round trip per state instead of two).  With the
+         * bounds a wave stays together until its whole 64-state block is done: lanes past the
+         * last state run along with an empty term list. */
         int s = from + tid;
+        const int send = bounds ? ((states + 63) & ~63) : states;
         EdgeRows nx;
         if (s < states) load_edge_rows(T, s, nx);
-        for (; s < states; s += B) {
+        for (; s < send; s += B) {
             const EdgeRows cur = nx;
+            const bool valid = s < states;
             if (s + B < states) load_edge_rows(T, s + B, nx);
-            if (!cur.dt) continue;
+            const bool tabled = valid && cur.dt;
+            if (!bounds && !tabled) continue;
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
              * of a group of slots are in flight together (the chain is latency bound). */
@@ -579,10 +689,10 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
 #pragma unroll
             for (int l = 0; l < 2; l++) {
                 int k = cur.tree[l];
-                msk[l] = k != RANGE_ ? 1u : 0u;
-                idx[l][0] = k != RANGE_ ? k : 0;
+                msk[l] = tabled && k != RANGE_ ? 1u : 0u;
+                idx[l][0] = tabled && k != RANGE_ ? k : 0;
                 wt[l][0] = 1.0f;
-                bool live = true;
+                bool live = tabled;
 #pragma unroll
                 for (int e = 0; e < FC_MAXE; e++) {
                     live = live && cur.rd[l][e] != NOEDGE;
@@ -591,6 +701,20 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
+#if FC_SCAN_SL && !FC_VARIANT_BIG
+            /* can the state be a candidate at this level at all (codec/approx.c:360-377)?  Its
+             * Gram diagonal and pool position: one read each per level and state */
+            /* rden: an UPPER bound of 1 / den is all that is needed (the table holds upper bounds):
+             * the hardware reciprocal (1 ulp) times (1 + 2^-21) instead of a division per slot */
+            float rden = 0.0f;
+            if (bounds) {
+                const unsigned us = (unsigned) (valid ? s : 0);
+                const float den = ldg(diag, qrow + us);
+                const bool cand = tabled && ldg(pos, us) >= 0 && !(den * rsize < MIN_NORM);
+                rden = cand ? __builtin_amdgcn_rcpf(den) * 1.00000047683715820312f : 0.0f;
+            }
+            float cb[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#endif
             constexpr int JG = 4;          /* slots per group: 4 x 2 x (FC_MAXE + 1) gathers in flight per lane (8: -5 %) */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
                 float v[JG][2][FC_MAXE + 1];
@@ -618,8 +742,20 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                         for (int i = 1; i <= FC_MAXE; i++)
                             if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
                     }
-                    stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
+                    if (tabled) stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
+#if FC_SCAN_SL && !FC_VARIANT_BIG
+                    cb[jj] = acc * acc * rden;
+#endif
                 }
+#if FC_SCAN_SL && !FC_VARIANT_BIG
+                if (bounds) {                                       /* uniform */
+                    wave_max4_l63(cb[0], cb[1], cb[2], cb[3]);
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++)
+                        if (j0 + jj < cnt && lane == 63)
+                            stg(cmax, (unsigned) ((slot0 + j0 + jj) * NB + (s >> 6)), cb[jj]);
+                }
+#endif
             }
         }
         __syncthreads();
@@ -1469,9 +1605,22 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
 /* aac snapshot slots of a depth: 0 entry, 1 after the linear combination; with prediction (big
  * build) 2 = resting model at entry, 3 / 4 = active / resting model after the recursion
  * (rec_coeff_model, rec_d_coeff_model of predict_range) */
+#if FC_VARIANT_BIG
 #define SNAP_AT(sh, depth, which) (SNAP(sh) + ((depth) * NSLOT(sh) + (which)) * (sh).n16)
+#else
+/* slot 0 of depth d is slot d; slot 1 exists for the block levels with children only and follows
+ * the depth slots: snap_b1 + d (the depth of a node is frame level - node level) */
+#define SNAP_AT(sh, depth, which) (SNAP(sh) + ((which) ? (sh).par.snap_b1 + (depth) : (depth)) * (sh).n16)
+#endif
 /* tree-model snapshots: slot 0 entry, slot 1 (prediction) after the recursion */
-#define TM_AT(sh, depth, which, ML) (SNAP_TM(sh) + ((depth) * TM_SLOTS(sh) + (which)) * (ML))
+/* uint4 per tree-model snapshot: both models (4 ML words) in the big build, the first one in the
+ * default build */
+#if FC_VARIANT_BIG
+#define TM_N16(ML) (ML)
+#else
+#define TM_N16(ML) ((2 * (ML) + 3) / 4)
+#endif
+#define TM_AT(sh, depth, which, ML) (SNAP_TM(sh) + ((depth) * TM_SLOTS(sh) + (which)) * TM_N16(ML))
 
 /* the same snapshots taken by the whole workgroup around a linear-combination search
  * (codec/subdivide.c:188-237): before it, models -> slot 0 (+ tree model); after it, models ->
@@ -1480,7 +1629,7 @@ __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, 
 {
     const int tid = threadIdx.x;
     if (tid < sh.n16) SNAP_AT(sh, depth, 0)[tid] = ((const uint4 *) &sh.cb)[tid];
-    else if (tid >= 96 && tid < 96 + ML)           /* n16 <= 82 (FC_MAXCOEFF_BIG), ML <= 26 */
+    else if (tid >= 96 && tid < 96 + TM_N16(ML))   /* n16 <= 82 (FC_MAXCOEFF_BIG), ML <= 26 */
         TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
     else if (tid == 128) fr.pool0 = sh.pool;
 #if FC_VARIANT_BIG
@@ -1573,12 +1722,12 @@ __device__ void snap_load_d(Sh &sh, int depth, int which)
 
 __device__ __forceinline__ void tm_save(Sh &sh, int depth, int ML, int which = 0)
 {
-    copy16(TM_AT(sh, depth, which, ML), (const uint4 *) sh.tm, ML);      /* 4*ML words */
+    copy16(TM_AT(sh, depth, which, ML), (const uint4 *) sh.tm, TM_N16(ML));
 }
 
 __device__ __forceinline__ void tm_load(Sh &sh, int depth, int ML, int which = 0)
 {
-    copy16((uint4 *) sh.tm, TM_AT(sh, depth, which, ML), ML);
+    copy16((uint4 *) sh.tm, TM_AT(sh, depth, which, ML), TM_N16(ML));
 }
 
 /* wfalib.c:152-180 */
@@ -1671,7 +1820,7 @@ __device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_s
     SFrame &r = sh.st[0];
     r.rg.x = r.rg.y = r.rg.image = r.rg.address = 0;
     r.rg.level = F.level; r.rg.tree = RANGE_;
-    for (int i = 0; i <= MAXED; i++) { r.rg.weight[i] = 0; r.rg.into[i] = 0; }
+    for (int i = 0; i < RANGE_E; i++) { r.rg.weight[i] = 0; r.rg.into[i] = 0; }
     r.rg.err = r.rg.tree_bits = r.rg.matrix_bits = r.rg.weights_bits = 0;
     r.max_costs = MAXCOSTS;
     r.y_state = y_state;
@@ -1730,7 +1879,14 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
  * compiler hoists every constant and LDS address of every phase into registers for the whole
  * loop, ~120 VGPRs, and the function then saves and restores 48 callee-saved registers through
  * scratch memory on every call (a memory round trip on the serial path, ~100 k times per frame). */
+#ifndef FC_SERIAL_LOOP
+#define FC_SERIAL_LOOP 0
+#endif
+#if FC_SERIAL_LOOP
+__device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+#else
 __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+#endif
 {
     const int ML = sh.par.ML;
     {
@@ -1875,15 +2031,21 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 break;
             }
             if (!fr.coop) {
+#if FC_VARIANT_BIG
                 fr.pool_lc = sh.pool;
                 snap_save(F, sh, sh.sp, 1);
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sh.sp, 0);
+#else
+                /* a node above the largest block level: no linear combination has touched the
+                 * models since the snapshot of its entry */
+                fr.pool_lc = sh.pool;
+#endif
             }
             if (rg.level > sh.lc_min) {
                 Range z;
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
-                for (int i = 0; i <= MAXED; i++) { z.weight[i] = 0; z.into[i] = 0; }
+                for (int i = 0; i < RANGE_E; i++) { z.weight[i] = 0; z.into[i] = 0; }
                 z.err = z.tree_bits = z.matrix_bits = z.weights_bits = 0;
 #if FC_VARIANT_BIG
                 z.nd_tree_bits = z.nd_weights_bits = z.mv_tree_bits = z.mv_coord_bits = 0; z.prediction = 0;
@@ -2196,7 +2358,11 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
 }
 
 /* advance the partition search until a data-parallel operation is required */
+#if FC_SERIAL_LOOP
+__device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+#else
 __device__ __forceinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+#endif
 {
     while (serial_step(F, sh))
         ;
@@ -2393,8 +2559,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #else
             const bool snap_lds = true, tm_lds = true;
 #endif
-            if ((snap_lds && (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16)
-                || (tm_lds && (F.level - F.lc_min + 3) * 4 * ML > SNAP_TM_WORDS) || F.coeff_nt > 16
+#if FC_VARIANT_BIG
+            const int snap_need = (F.level - F.lc_min + 3) * 2 * sh.n16;
+#else
+            const int snap_need = (F.level - F.lc_min + 3 + F.lc_max - F.lc_min) * sh.n16;
+            sh.par.snap_b1 = (F.level - F.lc_min + 3) - (F.level - F.lc_max);
+#endif
+            if ((snap_lds && snap_need > SNAP_POOL16)
+                || (tm_lds && (F.level - F.lc_min + 3) * 4 * TM_N16(ML) > SNAP_TM_WORDS) || F.coeff_nt > 16
                 || (F.P + 63) / 64 > NBLOCKMIN            /* block minima of the general scan */
                 || depth_need > FC_DEPTH
                 || F.max_elements > FC_MAXE               /* term slots of the table ops */
@@ -2527,6 +2699,16 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             __hip_atomic_store(&ring[i], (unsigned long long) F.slab_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+/* workgroups of this build a CU holds at once: what the build was compiled for (its launch bound
+ * caps the registers) unless its LDS allows fewer.  The launcher sizes the frame queue and the
+ * number of slabs by it.  (hipOccupancyMaxActiveBlocksPerMultiprocessor answered 1 and 2 for
+ * builds that demonstrably run 4 and 5 workgroups per CU: not used.) */
+extern "C" int FC_OCCUPANCY(void)
+{
+    const int by_lds = (int) (163840 / sizeof(Sh));
+    return by_lds < FC_WG_PER_CU ? (by_lds < 1 ? 1 : by_lds) : FC_WG_PER_CU;
 }
 
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,

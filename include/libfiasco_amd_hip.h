@@ -30,6 +30,11 @@ typedef struct fiasco_amd_stats {
      * of 64-candidate blocks whose survivors were fully evaluated */
     unsigned long long t_mpA, t_mpB, n_blockevals;
     unsigned long long dbg[8];      /* free-form developer counters */
+    /* states of the finished automata (sum / largest) and frames that were encoded a second time
+     * because the capacity guess of their slab was too small */
+    unsigned long long states_sum, states_max, reencodes;
+    /* frames launched per kernel build: default 256 / 512 threads, big 256 / 512 threads */
+    unsigned long long frames_by_build[4];
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

@@ -106,6 +106,15 @@
 #ifndef FC_REG_MB
 #define FC_REG_MB 0
 #endif
+/* FC_EST_RCP: the sweep's block minima are taken over a tight lower bound of the estimates
+ * (reciprocal instead of division, stage1<.., LBQ> in mp_device.inc) */
+#ifndef FC_EST_RCP
+#define FC_EST_RCP 1
+#endif
+/* FC_MIN4: block minima of the register scan four slots at a time (interleaved DPP chains) */
+#ifndef FC_MIN4
+#define FC_MIN4 1
+#endif
 #ifndef FC_SL_NEXT_TOUCH
 #define FC_SL_NEXT_TOUCH 0
 #endif

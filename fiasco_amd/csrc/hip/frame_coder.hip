@@ -321,6 +321,10 @@ struct Sh {
         const unsigned *l2_keys; const double *l2_vals; unsigned l2_mask;
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
         int snap_b1;               /* default build: first "after the linear combination" snapshot slot minus its depth */
+        /* automaton arrays for the serial lane: through the frame descriptor (a generic reference in
+         * the out-of-line search code) every access is a flat_ instruction behind a descriptor read */
+        int16_t *at_tree, *at_into, *at_pool; float *at_weight, *at_final; uint8_t *at_los, *at_dtype, *at_ycol;
+        uint16_t *at_x, *at_y; int color;
         float rpf_range, dc_range;
     } par;
     int      states;               /* wfa->states */
@@ -897,6 +901,9 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
     /* term lists of the new state s (slot 0 = tree child with weight 1 if any, then the
      * edges): twelve lanes read one row slot each (one memory round trip instead of a chain of
      * dependent ones), two lanes compact them into LDS; uniform for the whole workgroup */
+#if !FC_VARIANT_BIG
+    /* default build: store_new_state() has left the term lists in sh.gs_* */
+#else
     if (tid < 12) {
         const int l = tid / 6, e = tid % 6;
         sh.gs_raw_idx[l][e] = e == 0 ? (int) TREE(F, s, l) : (int) INTO(F, s, l, e - 1);
@@ -915,6 +922,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         for (; m <= MAXED; m++) { sh.gs_idx[l][m] = 0; sh.gs_w[l][m] = 0.0f; }   /* valid dummies */
     }
     __syncthreads();
+#endif
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
      * depends on level l-1 of OTHER states only (codec/control.c:205-258) */
     if (tid == B - 1) F.img[(size_t) s * F.NI] = F.final_d[s];
@@ -1068,11 +1076,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         }
 #endif
     if (tid == 0) {
-        int E = 0;
-        for (int l = 0; l < 2; l++) {
-            if (TREE(F, s, l) != RANGE_) E++;
-            for (int e = 0; INTO(F, s, l, e) != NOEDGE; e++) E++;
-        }
+        const int E = sh.gs_n[0] + sh.gs_n[1];       /* tree children + edges of the new state */
         sh.cnt.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
         sh.cnt.n_appends++;
     }
@@ -1754,6 +1758,100 @@ __device__ float final_distribution_dev(const DevFrame &F, int s)
 
 /* init_new_state (codec/subdivide.c:549-610): store the new state's rows; edge lists are
  * kept sorted by target like append_edge (codec/wfalib.c:233-275) */
+#if !FC_VARIANT_BIG
+/* The default build's form (<= 3 edges per label): table bases from LDS as global pointers, the
+ * edge lists sorted in registers (a dynamically indexed private array lives in scratch memory),
+ * the final distribution from the values at hand -- the terms' entries are read in one batch, not
+ * found again one dependent read at a time through the rows just stored. */
+__device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, int aux)
+{
+    const int s = sh.states, PA = sh.par.PA;
+    GLOBAL_AS int16_t *const tree = (GLOBAL_AS int16_t *) sh.par.at_tree, *const into = (GLOBAL_AS int16_t *) sh.par.at_into;
+    GLOBAL_AS int16_t *const posv = (GLOBAL_AS int16_t *) sh.par.pos, *const pool = (GLOBAL_AS int16_t *) sh.par.at_pool;
+    GLOBAL_AS float *const weight = (GLOBAL_AS float *) sh.par.at_weight, *const fin = (GLOBAL_AS float *) sh.par.at_final;
+    GLOBAL_AS uint16_t *const xs = (GLOBAL_AS uint16_t *) sh.par.at_x, *const ys = (GLOBAL_AS uint16_t *) sh.par.at_y;
+    short p = -1;
+    if (!aux && sh.pool.n < sh.pool.max_domains) {
+        p = (short) sh.pool.n;
+        pool[sh.pool.n++] = (short) s;
+    }
+    posv[s] = p;
+    fr.rrange.into[0] = NOEDGE;
+    fr.rrange.tree = s;
+    int   tr[2], i[2][3];
+    float w[2][3], fd_t[2], fd_e[2][3];
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const Range &ch = fr.child[l];
+        tr[l] = ch.tree;
+        bool live = true;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {                     /* NOEDGE terminated; missing: sorts last */
+            live = live && ch.into[e] != NOEDGE;
+            i[l][e] = live ? (int) ch.into[e] : 0x7fff;
+            w[l][e] = live ? ch.weight[e] : 0.0f;
+        }
+        /* ascending by target (append_edge, codec/wfalib.c:233-275; targets are distinct) */
+#define CSWAP(a, b) if (i[l][a] > i[l][b]) { int ti = i[l][a]; i[l][a] = i[l][b]; i[l][b] = ti; float tw = w[l][a]; w[l][a] = w[l][b]; w[l][b] = tw; }
+        CSWAP(0, 1) CSWAP(1, 2) CSWAP(0, 1)
+#undef CSWAP
+        /* every term's final distribution entry requested at once (missing terms: state 0) */
+        fd_t[l] = fin[tr[l] != RANGE_ ? tr[l] : 0];
+#pragma unroll
+        for (int e = 0; e < 3; e++) fd_e[l][e] = fin[i[l][e] != 0x7fff ? i[l][e] : 0];
+    }
+    float f = 0;                                          /* wfalib.c:152-180 */
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const Range &ch = fr.child[l];
+        tree[l * PA + s] = (short) tr[l];
+        xs[l * PA + s] = (uint16_t) ch.x;
+        ys[l * PA + s] = (uint16_t) ch.y;
+        if (tr[l] != RANGE_) f += fd_t[l];
+#pragma unroll
+        for (int e = 0; e < 3; e++)
+            if (i[l][e] != 0x7fff) {
+                into[(l * 6 + e) * PA + s] = (short) i[l][e];
+                weight[(l * 6 + e) * PA + s] = w[l][e];
+                f += w[l][e] * fd_e[l][e];
+            }
+        const int ne = (i[l][0] != 0x7fff) + (i[l][1] != 0x7fff) + (i[l][2] != 0x7fff);
+        into[(l * 6 + ne) * PA + s] = NOEDGE;
+        /* y_column (codec/subdivide.c:560-567), see the general form below */
+        if (sh.par.color) {
+            int yc = 0;
+#pragma unroll
+            for (int e = 0; e < 3; e++) if (i[l][e] != 0x7fff && i[l][e] == fr.ny[l]) yc = 1;
+            ((GLOBAL_AS uint8_t *) sh.par.at_ycol)[l * PA + s] = (uint8_t) yc;
+        }
+    }
+    fin[s] = f / 2;
+    /* the term lists op_append works from (slot 0 = tree child with weight 1 if any, then the edges
+     * in stored order; unused slots: valid dummies), so that it need not read the rows back */
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        int m = 0;
+        const int c = tr[l] != RANGE_;
+        sh.gs_c[l] = c;
+        int   gi[4]; float gw[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { gi[a] = 0; gw[a] = 0.0f; }
+        if (c) { gi[0] = tr[l]; gw[0] = 1.0f; m = 1; }
+#pragma unroll
+        for (int e = 0; e < 3; e++)
+            if (i[l][e] != 0x7fff) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a == m) { gi[a] = i[l][e]; gw[a] = w[l][e]; }
+                m++;
+            }
+        sh.gs_n[l] = m;
+#pragma unroll
+        for (int a = 0; a <= MAXED; a++) { sh.gs_idx[l][a] = a < 4 ? gi[a < 4 ? a : 0] : 0; sh.gs_w[l][a] = a < 4 ? gw[a < 4 ? a : 0] : 0.0f; }
+    }
+    ((GLOBAL_AS uint8_t *) sh.par.at_los)[s] = (uint8_t) fr.rrange.level;
+    ((GLOBAL_AS uint8_t *) sh.par.at_dtype)[s] = aux ? 0 : 2;
+}
+#else
 __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, int aux)
 {
     const int s = sh.states;
@@ -1801,6 +1899,7 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
     F.level_of_state[s] = (uint8_t) fr.rrange.level;
     F.domain_type[s] = aux ? 0 : 2;
 }
+#endif
 
 /* auxiliary state joining two band trees (codec/coder.c:803-833) */
 __device__ int append_join_state(DevFrame &__restrict__ F, Sh &__restrict__ sh, int t0, int t1, int level)
@@ -2607,6 +2706,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
         sh.par.gram = F.gram; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
         sh.par.d5 = F.d5; sh.par.d4 = F.d4;
+        sh.par.at_tree = F.tree; sh.par.at_into = F.into; sh.par.at_pool = F.pool_states; sh.par.at_weight = F.weight;
+        sh.par.at_final = F.final_d; sh.par.at_los = F.level_of_state; sh.par.at_dtype = F.domain_type;
+        sh.par.at_ycol = F.ycol; sh.par.at_x = F.x; sh.par.at_y = F.y; sh.par.color = F.color;
         sh.par.l2_keys = F.l2_keys; sh.par.l2_vals = F.l2_vals; sh.par.l2_mask = F.l2_mask;
         sh.par.max_elements = F.max_elements; sh.par.rpf_mant = F.rpf_mant; sh.par.dc_mant = F.dc_mant;
         sh.par.sy = F.sy; sh.par.dcs = F.dcs; sh.par.gl0 = F.gl0; sh.par.images_level = F.images_level;

@@ -56,9 +56,9 @@ static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
 }
 
 /* The 256-thread default build keeps a shorter stack and smaller snapshot pools in LDS than the
- * 512-thread one (frame_coder.hip: FC_MAXDEPTH_NARROW, FC_SNAP16_NARROW, FC_SNAPTM_NARROW -- sized
+ * wide one (frame_coder.hip: FC_MAXDEPTH_NARROW, FC_SNAP16_NARROW, FC_SNAPTM_NARROW -- sized
  * for what the stock reference accepts, level <= 22); a frame beyond them is given to the
- * 512-thread build whatever the size of the launch. */
+ * wide build whatever the size of the launch. */
 static bool needs_wide_variant(const fa_cparams *cp)
 {
     unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
@@ -949,7 +949,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                 S->lender0 = (int) k; S->lenders = 1;
                 S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
-                 * launch will use (512-thread build for P > 3072: one per CU) */
+                 * launch will use (wide build for P > 3072: one per CU) */
                 S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only);
                 if (getenv("FIASCO_AMD_QUEUE_SLABS") && atoi(getenv("FIASCO_AMD_QUEUE_SLABS")) > 0)
                     S->lender_cap = (size_t) atoi(getenv("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
@@ -1198,7 +1198,7 @@ static bool launch_wave(Staged *S)
         if (S->slots[k].staged && !S->slots[k].done) batch.push_back(k);
     if (batch.empty()) return false;
     /* one launch per kernel build (frame_coder.hip): geometry {default, big} x workgroup width
-     * {256, 512 threads}.  The wide builds take launches with no more frames than CUs (the
+     * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
     size_t group_n[4] = { 0, 0, 0, 0 }, group_lend[4] = { 0, 0, 0, 0 }, group_borrow[4] = { 0, 0, 0, 0 };

@@ -42,18 +42,22 @@
 #include <math.h>
 #include "frame_coder.h"
 
-/* FC_VARIANT_WIDE: 512 threads per frame instead of 256 -- for launches with no more frames than
- * CUs and for frames with more states than 12 x 256 (4K): twice the lanes per frame, 18
- * register slots per lane (9216 states), one workgroup per CU */
+/* FC_VARIANT_WIDE: FC_WIDE_B (512, or 1024 for the default geometry: csrc/Makefile) threads per
+ * frame instead of 256 -- for launches with no more frames than CUs and for frames with more
+ * states than 12 x 256 (4K): more lanes per frame, 9216 states in the register slots, one
+ * workgroup per CU */
 #ifndef FC_VARIANT_WIDE
 #define FC_VARIANT_WIDE 0
 #endif
 #if FC_VARIANT_WIDE
-#define B       512
+#ifndef FC_WIDE_B
+#define FC_WIDE_B 512
+#endif
+#define B       FC_WIDE_B
 #if defined(FC_VARIANT_BIG) && FC_VARIANT_BIG
 #define FC_KREG 12               /* 6144 states with 4 orthogonal vectors each in registers */
 #else
-#define FC_KREG 18
+#define FC_KREG (9216 / FC_WIDE_B)
 #endif
 #else
 #define B       FC_BLOCK

@@ -105,11 +105,6 @@
 #ifndef FC_SCAN_SL
 #define FC_SCAN_SL 0
 #endif
-/* FC_REG_MB: the register-resident scan replays its ordered rounds over up to one block per wave
- * (mp_reg.inc) instead of one block per round */
-#ifndef FC_REG_MB
-#define FC_REG_MB 0
-#endif
 /* FC_EST_RCP: the sweep's block minima are taken over a tight lower bound of the estimates
  * (reciprocal instead of division, stage1<.., LBQ> in mp_device.inc) */
 #ifndef FC_EST_RCP
@@ -287,8 +282,8 @@ struct Sh {
     int      apx_stage, apx_it, apx_more;   /* retry plan of approximate_range (lane 0) */
 #endif
     float    blockmin[NBLOCKMIN];
-#if FC_SCAN_SL || FC_REG_MB
-    /* mp_sl.inc / mp_reg.inc: (estimate, costs) of the candidates of the blocks of a round, per round parity */
+#if FC_SCAN_SL
+    /* mp_sl.inc: (estimate, costs) of the candidates of the blocks of a round, per round parity */
     float    slx[2][2][B / 64][64];
 #endif
     float    pixels[FC_PIXELS];

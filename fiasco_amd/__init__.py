@@ -61,7 +61,7 @@ class Stats(ctypes.Structure):
                 ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong),
                 ("dbg", ctypes.c_ulonglong * 8), ("states_sum", ctypes.c_ulonglong),
                 ("states_max", ctypes.c_ulonglong), ("reencodes", ctypes.c_ulonglong),
-                ("frames_by_build", ctypes.c_ulonglong * 4)]
+                ("frames_by_build", ctypes.c_ulonglong * 5)]
 
 
 def build(verbose=False):

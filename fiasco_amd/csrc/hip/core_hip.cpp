@@ -29,6 +29,8 @@ extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, unsigned nlend, un
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+extern "C" void fc_launch_wide_tri(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 
@@ -387,14 +389,15 @@ struct Layout {
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
 static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix,
-                          int max_save, int inter, int plevels, int color)
+                          int max_save, int inter, int plevels, int color, bool tri)
 {
     Layout L;
     memset(&L, 0, sizeof L);             /* compared with memcmp (frame queue) */
     size_t o = 0;
     L.max_save = max_save;
 #define CARVE(field, bytes) do { L.field = o; o = align_up(o + (bytes), 256); } while (0)
-    CARVE(gram, (size_t) NL * P * P * 4);
+    /* Gram tables: full symmetric, or (tri) the lower triangle with packed rows + a row of slack */
+    CARVE(gram, tri ? (size_t) NL * ((size_t) P * (P + 1) / 2 + P) * 4 : (size_t) NL * P * P * 4);
     CARVE(diag, (size_t) NL * P * 4);
     CARVE(ipis, (size_t) NS * P * 4);
     CARVE(cmax, (size_t) NS * (P / 64) * 4);        /* per heap slot and 64-state block (frame_coder.hip op_ipis) */
@@ -499,6 +502,7 @@ struct FrameSlot {
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
     bool     wide_only = false;  /* default geometry, but beyond the 256-thread build's LDS pools */
+    bool     tri = false;        /* triangular Gram tables (half the slab; the wide_tri build of the kernel) */
     bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
@@ -554,7 +558,7 @@ struct Staged {
     int       lender0 = -1;        /* first slot with a slab of the queue's layout */
     Layout    qL;                  /* that layout and capacity (the slot itself may be re-staged larger) */
     int       qP = 0, qPA = 0;
-    bool      qbig = false;        /* kernel build of the queue's frames */
+    bool      qbig = false, qtri = false;   /* kernel build of the queue's frames */
     size_t    lenders = 0, borrowers = 0, lender_cap = 0;
     char     *qpix = nullptr;      /* pixel planes of the borrowers */
     size_t    qpix_bytes = 0, qpix_used = 0;
@@ -587,6 +591,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.rpf_mant = (int) cp->rpf.mantissa_bits; F.dc_mant = (int) cp->dc_rpf.mantissa_bits;
     F.rpf_range = cp->rpf.range; F.dc_range = cp->dc_rpf.range;
     F.P = fs.P; F.PA = fs.PA;
+    F.gram_ls = fs.tri ? (unsigned) ((size_t) fs.P * (fs.P + 1) / 2 + fs.P) : (unsigned) fs.P * (unsigned) fs.P;
     F.color = job->image->color ? 1 : 0;
     F.chroma_max = (int) cp->chroma_max_states;
     F.chroma_decrease = cp->chroma_decrease;
@@ -682,7 +687,7 @@ static void slot_layout(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri);
 }
 
 /* ---- frame queue: which frames may share slabs ---- */
@@ -698,7 +703,8 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 static bool queue_layout(const Staged *S, const FrameSlot &fs)
 {
     if (S->lender0 < 0) return false;
-    return fs.P == S->qP && fs.PA == S->qPA && fs.big == S->qbig && memcmp(&fs.L, &S->qL, sizeof(Layout)) == 0;
+    return fs.P == S->qP && fs.PA == S->qPA && fs.big == S->qbig && fs.tri == S->qtri
+           && memcmp(&fs.L, &S->qL, sizeof(Layout)) == 0;
 }
 
 static void fill_frame(FrameSlot &fs, const fa_job *job);
@@ -758,7 +764,7 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     /* developer aid: FIASCO_AMD_POISON=<byte> fills the slab first -- the kernel must write every
      * cell before it reads it, whatever an earlier frame left there */
@@ -882,6 +888,8 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.P = (int) align_up(guess, 64);
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
+        /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
+        if (!fs.big && getenv("FIASCO_AMD_FORCE_TRI")) fs.tri = true;
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
@@ -921,7 +929,20 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
             if (hipMalloc((void **) &S->qpix, need * frames) == hipSuccess) { S->qpix_bytes = need * frames; S->qpix_used = 0; }
             else { S->qpix = nullptr; (void) hipGetLastError(); }
         }
-        if (hbm_bound)
+        bool still_bound = hbm_bound;
+        if (hbm_bound) {
+            /* first remedy: the triangular Gram tables -- half the slab; the kernel build that reads
+             * them exists for the default geometry at the wide workgroup (frames with more than 3072
+             * states: 4K), where memory is what keeps CUs idle.  FIASCO_AMD_NO_TRI keeps the full tables. */
+            for (size_t k = 0; k < S->slots.size(); k++) {
+                FrameSlot &fs = S->slots[k];
+                if (!fs.big && fs.P > 12 * 256 && !getenv("FIASCO_AMD_NO_TRI")) fs.tri = true;
+            }
+            FrameSlot probe2 = S->slots[0];
+            slot_layout(S, probe2);
+            still_bound = probe2.L.total * want > free_b + pooled;
+        }
+        if (still_bound)
             for (size_t k = 0; k < S->slots.size(); k++) {
                 FrameSlot &fs = S->slots[k];
                 const fa_job *job = &jobs[fs.job];
@@ -947,7 +968,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         if (stage_slot(S, fs)) {
             if (elig && S->lender0 < 0) {
                 S->lender0 = (int) k; S->lenders = 1;
-                S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big;
+                S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big; S->qtri = fs.tri;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (wide build for P > 3072: one per CU) */
                 S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only);
@@ -1157,13 +1178,13 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
  * when the same frame is laid out for two different slabs, plus pack_src */
 static bool queue_resources(Staged *S, size_t frames)
 {
-    if (4 * frames > S->ring_n) {
+    if (5 * frames > S->ring_n) {
         if (S->d_ring) (void) hipFree(S->d_ring);
         S->d_ring = nullptr; S->ring_n = 0;
-        if (hipMalloc((void **) &S->d_ring, sizeof(unsigned long long) * 4 * frames) != hipSuccess) { (void) hipGetLastError(); return false; }
-        S->ring_n = 4 * frames;
+        if (hipMalloc((void **) &S->d_ring, sizeof(unsigned long long) * 5 * frames) != hipSuccess) { (void) hipGetLastError(); return false; }
+        S->ring_n = 5 * frames;
     }
-    if (!S->d_queue && hipMalloc((void **) &S->d_queue, 8 * sizeof(unsigned)) != hipSuccess) {
+    if (!S->d_queue && hipMalloc((void **) &S->d_queue, 10 * sizeof(unsigned)) != hipSuccess) {
         S->d_queue = nullptr; (void) hipGetLastError(); return false;
     }
     if (!S->ptrmask_ready) {
@@ -1201,7 +1222,7 @@ static bool launch_wave(Staged *S)
      * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[4] = { 0, 0, 0, 0 }, group_lend[4] = { 0, 0, 0, 0 }, group_borrow[4] = { 0, 0, 0, 0 };
+    size_t group_n[5] = { 0, 0, 0, 0, 0 }, group_lend[5] = { 0, 0, 0, 0, 0 }, group_borrow[5] = { 0, 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1211,12 +1232,12 @@ static bool launch_wave(Staged *S)
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
-        for (int g = 0; g < 4; g++)
+        for (int g = 0; g < 5; g++)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
-                    if ((int) fs.big * 2 + (int) wide != g) continue;
+                    if ((fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
@@ -1274,9 +1295,9 @@ static bool launch_wave(Staged *S)
         /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
         unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
         if (getenv("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(getenv("FIASCO_AMD_QUEUE_WAIT_MS"));
-        static const launch_fn launch[4] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide };
+        static const launch_fn launch[5] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri };
         size_t first = 0;
-        for (int g = 0; g < 4 && !fail; g++) {
+        for (int g = 0; g < 5 && !fail; g++) {
             size_t plain = group_n[g], at = first;
             if (group_borrow[g]) {
                 /* the queue: group_lend[g] frames with slabs first, then the frames that borrow one */

@@ -9,6 +9,9 @@
  *                           (reference ip_states_state, codec/cwfa.h:86, is lower
  *                           triangular per level; stored full so that both the
  *                           Gram-Schmidt row sweep and the row append read contiguous rows)
+ *           or [NL][P(P+1)/2 + P]: the lower triangle with packed rows, for the frames whose
+ *                           full tables HBM cannot hold for every CU (4K): half the memory, the
+ *                           sweep gathers the part of a row behind the diagonal from the column
  *    diag   [NL][P]    f32  Gram diagonal (matching-pursuit denominators)
  *    ipis   [NS][P]    f32  <range sub-block, state>, heap slot major
  *                           (reference ip_images_state, codec/cwfa.h:89, is state major)
@@ -60,6 +63,9 @@ typedef struct DevFrame {
     int      rpf_mant, dc_mant;
     float    rpf_range, dc_range;
     int      P;            /* pitch / capacity of the per-state TABLES (states with images) */
+    unsigned gram_ls;      /* floats per level of the Gram tables: P x P (full symmetric layout), or
+                            * P (P + 1) / 2 + P (lower triangle with packed rows -- the FC_GRAM_TRI build of
+                            * the kernel --, + one row of slack) */
     int      PA;           /* pitch / capacity of the automaton arrays (all states, PA >= P) */
     int      color;        /* 3 bands Y, Cb, Cr (codec/coder.c:775-800) */
     int      chroma_max;   /* size of the chroma domain list (rle_chroma, domain-pool.c:854-879) */

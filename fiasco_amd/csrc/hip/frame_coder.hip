@@ -84,9 +84,15 @@
 #define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 2)
 #else
 #if FC_VARIANT_WIDE
+#if defined(FC_GRAM_TRI) && FC_GRAM_TRI
+#define FC_KERNEL    fiasco_frame_kernel_wide_tri
+#define FC_LAUNCH    fc_launch_wide_tri
+#define FC_OCCUPANCY fc_occupancy_wide_tri
+#else
 #define FC_KERNEL    fiasco_frame_kernel_wide
 #define FC_LAUNCH    fc_launch_wide
 #define FC_OCCUPANCY fc_occupancy_wide
+#endif
 #else
 #define FC_KERNEL    fiasco_frame_kernel
 #define FC_LAUNCH    fc_launch
@@ -315,7 +321,7 @@ struct Sh {
     struct {
         int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease;
         /* the same for the matching pursuit: table bases and quantiser parameters */
-        float *gram, *diag, *ipis; int16_t *pos;
+        float *gram, *diag, *ipis; int16_t *pos; unsigned gram_ls;
         float *d5, *d4;            /* big build: the active level-5 / level-4 dot tables */
         const unsigned *l2_keys; const double *l2_vals; unsigned l2_mask;
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
@@ -373,18 +379,29 @@ __device__ __forceinline__ int qac_shift(int index)
 
 /* ------------------------------------------------------------------ table access */
 
-#define GRAM(F, q)   ((F).gram + (size_t) (q) * (F).P * (F).P)
+/* Gram tables, two layouts (frame_coder.h): full symmetric P x P per level, or -- FC_GRAM_TRI,
+ * the build for frames whose full tables HBM cannot hold for every CU (4K) -- the lower triangle
+ * with packed rows, <a, b> with a >= b at TRI(a) + b.  The levels are gram_ls floats apart. */
+#ifndef FC_GRAM_TRI
+#define FC_GRAM_TRI 0
+#endif
+#define TRI(a)       ((unsigned) (a) * ((unsigned) (a) + 1u) / 2u)
+#define GROW(a, P)   (FC_GRAM_TRI ? TRI(a) : (unsigned) (a) * (unsigned) (P))     /* start of row a in a level */
+#define GRAM(F, q)   ((F).gram + (size_t) (q) * (F).gram_ls)
 /* the same through the LDS copy of the table base (no descriptor read on the hot path) */
-#define PGRAM(sh, q)  ((sh).par.gram + (size_t) (q) * (sh).par.P * (sh).par.P)
+#define PGRAM(sh, q)  ((sh).par.gram + (size_t) (q) * (sh).par.gram_ls)
 #define TREE(F, s, l)        ((F).tree[(l) * (F).PA + (s)])
 #define INTO(F, s, l, e)     ((F).into[((l) * 6 + (e)) * (F).PA + (s)])
 #define WEIGHT(F, s, l, e)   ((F).weight[((l) * 6 + (e)) * (F).PA + (s)])
+
+__device__ __forceinline__ float gram_load(const float *G, int P, int a, int b, int flim);
+#define NOFLIM 0x7fffffff        /* every entry is stored both ways (the basis states) */
 
 /* one Gram entry at table level q >= 1 from level q-1 (codec/ip.c:213-257) */
 __device__ float gram_entry(const DevFrame &F, int q, int s1, int s2)
 {
     const float *G = GRAM(F, q - 1);
-    const size_t P = (size_t) F.P;
+    const int P = F.P;
     float ip = 0;
     for (int label = 0; label < 2; label++) {
         int d1, d2;
@@ -392,17 +409,17 @@ __device__ float gram_entry(const DevFrame &F, int q, int s1, int s2)
         int t2 = TREE(F, s2, label);
         if ((d1 = TREE(F, s1, label)) != RANGE_) {
             sum = 0;
-            if (t2 != RANGE_) sum = G[(size_t) d1 * P + t2];
+            if (t2 != RANGE_) sum = gram_load(G, P, d1, t2, NOFLIM);
             for (int e2 = 0; (d2 = INTO(F, s2, label, e2)) != NOEDGE; e2++)
-                sum += WEIGHT(F, s2, label, e2) * G[(size_t) d1 * P + d2];
+                sum += WEIGHT(F, s2, label, e2) * gram_load(G, P, d1, d2, NOFLIM);
             ip += sum;
         }
         for (int e1 = 0; (d1 = INTO(F, s1, label, e1)) != NOEDGE; e1++) {
             float w1 = WEIGHT(F, s1, label, e1);
             sum = 0;
-            if (t2 != RANGE_) sum = G[(size_t) d1 * P + t2];
+            if (t2 != RANGE_) sum = gram_load(G, P, d1, t2, NOFLIM);
             for (int e2 = 0; (d2 = INTO(F, s2, label, e2)) != NOEDGE; e2++)
-                sum += WEIGHT(F, s2, label, e2) * G[(size_t) d1 * P + d2];
+                sum += WEIGHT(F, s2, label, e2) * gram_load(G, P, d1, d2, NOFLIM);
             ip += w1 * sum;
         }
     }
@@ -431,11 +448,14 @@ __device__ float gram_dot4(const DevFrame &F, int s1, int s2)
 }
 #endif
 
+/* s >= t */
 __device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
 {
     float *G = GRAM(F, q);
-    G[(size_t) s * F.P + t] = v;
+    G[GROW(s, F.P) + (unsigned) t] = v;
+#if !FC_GRAM_TRI
     G[(size_t) t * F.P + s] = v;
+#endif
     if (s == t) F.diag[(size_t) q * F.P + s] = v;
 }
 
@@ -449,11 +469,33 @@ __device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
  */
 #define GRAM_FB 32
 
+/* position of <a, b> in a level.  Triangle: whichever of the two is larger names the row. */
+__device__ __forceinline__ unsigned gram_idx(int P, int a, int b, int flim)
+{
+#if FC_GRAM_TRI
+    return a >= b ? TRI(a) + (unsigned) b : TRI(b) + (unsigned) a;
+#else
+    const bool mirror = b > a && b >= flim;
+    return mirror ? (unsigned) b * (unsigned) P + (unsigned) a : (unsigned) a * (unsigned) P + (unsigned) b;
+#endif
+}
 __device__ __forceinline__ float gram_load(const float *G, int P, int a, int b, int flim)
 {
-    const bool mirror = b > a && b >= flim;
-    return mirror ? G[(size_t) b * P + a] : G[(size_t) a * P + b];
+    return G[gram_idx(P, a, b, flim)];
 }
+
+#if FC_GRAM_TRI
+/*
+ *  The triangle.  A new state writes its row (entries t <= s, contiguous) and nothing else; the
+ *  sweep of a matching-pursuit step reads the chosen state's row up to the diagonal and, for the
+ *  candidates behind it, the chosen state's COLUMN -- one 4-byte gather per candidate, a whole
+ *  line of HBM traffic each.  Half the memory per frame: at 4K, where the full tables allow slabs
+ *  for only half the CUs, that doubles the frames in flight (16.2 -> 24.6 frames/s); at 1080p,
+ *  where every CU has its four frames anyway, the gathers cost 28 % (547 -> 392 frames/s) --
+ *  which is why the layout is a property of the kernel build and the launcher picks by memory.
+ */
+__device__ __forceinline__ void gram_flush(const DevFrame &, Sh &, int) { }
+#else
 
 __device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int upto)
 {
@@ -484,6 +526,7 @@ __device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, 
     __syncthreads();
     if (tid == 0) sh.flim = flim;
 }
+#endif
 
 /* state image element (codec/control.c:205-258): level l >= 1, position i */
 __device__ float image_elem(const DevFrame &F, int s, int l, int i)
@@ -951,6 +994,8 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         const int flim = __builtin_amdgcn_readfirstlane(sh.flim);
         const int Pu = __builtin_amdgcn_readfirstlane(P);
         s = __builtin_amdgcn_readfirstlane(s);
+        const unsigned LS = (unsigned) __builtin_amdgcn_readfirstlane((int) F.gram_ls);   /* floats per table level */
+        const unsigned rs = GROW(s, Pu);               /* start of the new state's row in a level */
         GLOBAL_AS float *const gram = uniform_ptr(F.gram);
         GLOBAL_AS float *const diag = uniform_ptr(F.diag);
         AutoTabs T;
@@ -999,7 +1044,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                 for (int k = 0; k < 16; k++) { a4[k] = ldg(imgT4, (unsigned) (k * Pu + s)); b4[k] = ldg(imgT4, (unsigned) (k * Pu + t)); }
 #pragma unroll
                 for (int k = 0; k < 16; k++) v4 += a4[k] * b4[k];
-                stg(gram, (unsigned) (s * Pu + t), v4);
+                stg(gram, rs + (unsigned) t, v4);
                 if (s == t) stg(diag, (unsigned) s, v4);
                 q1 = 2;
             }
@@ -1008,7 +1053,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                 float v0 = 0;                         /* codec/ip.c:297-323, sequential */
 #pragma unroll
                 for (int k = 0; k < 32; k++) v0 += vs[k] * vt[k];
-                stg(gram + (size_t) (q1 - 1) * Pu * Pu, (unsigned) (s * Pu + t), v0);
+                stg(gram, (unsigned) (q1 - 1) * LS + rs + (unsigned) t, v0);
                 if (s == t) stg(diag, (unsigned) ((q1 - 1) * Pu + s), v0);
             }
             for (int q = q1; q < F.NL; q++) {
@@ -1016,7 +1061,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                  * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply.
                  * All gathers of a label (terms(s) x 6 slots of t) are issued before the first
                  * is used; dead term slots of t read a valid dummy entry (no per-lane branch). */
-                GLOBAL_AS const float *G = gram + (size_t) (q - 1) * Pu * Pu;
+                GLOBAL_AS const float *G = gram + (size_t) (q - 1) * LS;
                 float ip = 0;
                 float g[2][FC_MAXE + 1][FC_MAXE + 1];
 #pragma unroll
@@ -1028,9 +1073,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                         const int A = __builtin_amdgcn_readfirstlane(sh.gs_idx[l][a]);
 #pragma unroll
                         for (int b = 0; b <= FC_MAXE; b++) {
-                            const int bb = i2[l][b];
-                            const bool mirror = bb > A && bb >= flim;     /* gram_load() */
-                            g[l][a][b] = ldg(G, (unsigned) (mirror ? bb * Pu + A : A * Pu + bb));
+                            g[l][a][b] = ldg(G, gram_idx(Pu, A, i2[l][b], flim));
                         }
                     }
                 }
@@ -1050,7 +1093,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                         else ip += sh.gs_w[l][a] * sum;
                     }
                 }
-                stg(gram + (size_t) q * Pu * Pu, (unsigned) (s * Pu + t), ip);
+                stg(gram, (unsigned) q * LS + rs + (unsigned) t, ip);
                 if (s == t) stg(diag, (unsigned) (q * Pu + s), ip);
             }
         }
@@ -1528,7 +1571,7 @@ __device__ void pred_save_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, 
     if ((sh.pred_saved[idx >> 5] >> (idx & 31)) & 1u) return;
     if (!F.sv_auto[idx].dtype) return;                 /* the displaced state had no tables */
     for (int q = 0; q < F.NL; q++) {
-        const float *G = GRAM(F, q) + (size_t) s * P;
+        const float *G = GRAM(F, q) + GROW(s, P);
         float *dst = F.sv_gram + ((size_t) idx * F.NL + q) * P;
         for (int t = tid; t <= s; t += B) dst[t] = G[t];
     }
@@ -1589,7 +1632,7 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
             if (!((sh.pred_saved[idx >> 5] >> (idx & 31)) & 1u)) continue;      /* uniform */
             const int s = fr.states + idx;
             for (int q = 0; q < F.NL; q++) {
-                float *G = GRAM(F, q) + (size_t) s * P;
+                float *G = GRAM(F, q) + GROW(s, P);
                 const float *src = F.sv_gram + ((size_t) idx * F.NL + q) * P;
                 for (int t = tid; t <= s; t += B) G[t] = src[t];
             }
@@ -2703,7 +2746,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.par.lc_max = F.lc_max; sh.par.width = F.width; sh.par.height = F.height;
         sh.par.limit_states = F.limit_states; sh.par.PA = F.PA; sh.par.P = F.P; sh.par.ML = F.ML;
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
-        sh.par.gram = F.gram; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
+        sh.par.gram = F.gram; sh.par.gram_ls = F.gram_ls; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
         sh.par.d5 = F.d5; sh.par.d4 = F.d4;
         sh.par.at_tree = F.tree; sh.par.at_into = F.into; sh.par.at_pool = F.pool_states; sh.par.at_weight = F.weight;
         sh.par.at_final = F.final_d; sh.par.at_los = F.level_of_state; sh.par.at_dtype = F.domain_type;

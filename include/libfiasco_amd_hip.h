@@ -33,8 +33,9 @@ typedef struct fiasco_amd_stats {
     /* states of the finished automata (sum / largest) and frames that were encoded a second time
      * because the capacity guess of their slab was too small */
     unsigned long long states_sum, states_max, reencodes;
-    /* frames launched per kernel build: default 256 / 512 threads, big 256 / 512 threads */
-    unsigned long long frames_by_build[4];
+    /* frames launched per kernel build: default 256 / 1024 threads, big 256 / 512 threads, default
+     * 1024 threads with triangular Gram tables */
+    unsigned long long frames_by_build[5];
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

@@ -26,7 +26,16 @@
 #include <string.h>
 #include <ctype.h>
 #include <math.h>
+#include <time.h>
 #include "fa_host.h"
+
+/* developer aid: FIASCO_AMD_SEQ_TIMING=1 prints where a sweep spends its time (stderr) */
+static double seq_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
 
 #define YCOL_UNSET 2          /* y_column entry the frame did not write */
 
@@ -202,6 +211,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     unsigned *who = (unsigned *) calloc(s->ngop ? s->ngop : 1, sizeof *who);
     unsigned nrun = 0, g, r, step, maxlen = 0;
     int rc = 0;
+    double t_prep = 0, t_core = 0, t_dec = 0, t0;
     if (!run || !jobs || !ims || !who) { fa_set_error("Out of memory!"); goto out; }
     for (g = 0; g < s->ngop; g++) {
         unsigned k;
@@ -213,6 +223,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
         nrun++;
     }
     for (step = 0; step < maxlen; step++) {
+        t0 = seq_now();
         unsigned nb = 0, b;
         for (r = 0; r < nrun; r++) {
             gop_run *q = &run[r];
@@ -267,7 +278,9 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             who[nb++] = r;
         }
         if (!nb) continue;
+        t_prep += seq_now() - t0; t0 = seq_now();
         (void) fa_core_encode_frames(nb, jobs);
+        t_core += seq_now() - t0; t0 = seq_now();
         for (b = 0; b < nb; b++) {
             gop_run *q = &run[who[b]];
             const unsigned k = s->gfirst[q->g] + step;
@@ -291,7 +304,11 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             }
             fa_image_free(ims[b]); ims[b] = NULL;
         }
+        t_dec += seq_now() - t0;
     }
+    if (getenv("FIASCO_AMD_SEQ_TIMING"))
+        fprintf(stderr, "fa_seq_search: %u GOPs, %u steps: prepare %.2f s, core %.2f s, decode %.2f s\n",
+                nrun, maxlen, t_prep, t_core, t_dec);
     for (r = 0; r < nrun; r++) {
         s->carry_out[run[r].g] = run[r].carry;
         s->gdone[run[r].g] = 1;

@@ -149,7 +149,7 @@ enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
 /* edge slots of a range record: the vectors a build can keep plus the terminator (the stack of
  * range records is a third of the default build's LDS) */
 #define RANGE_E (FC_MAXE + 1)
-struct Range {
+struct __attribute__((aligned(16))) Range {     /* copied as 128-bit LDS words by the serial lane */
     int   x, y, image, address, level, tree;
     float weight[RANGE_E];
     short into[RANGE_E];
@@ -168,7 +168,7 @@ struct Pool {                    /* rle model, codec/domain-pool.c:621-630 */
     unsigned short d0_yindex, d0_n;
 };
 
-struct SFrame {
+struct __attribute__((aligned(16))) SFrame {
     Range rg, lrange, rrange, child[2];
     Pool  pool0, pool_lc;
     float max_costs, lincomb, subdiv, ret, price;
@@ -2032,20 +2032,22 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 #ifndef FC_SERIAL_LOOP
 #define FC_SERIAL_LOOP 0
 #endif
-#if FC_SERIAL_LOOP
-__device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh)
-#else
-__device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh)
-#endif
+/* sp / phase: the stack pointer and the phase of the frame on top of the stack, held by the caller
+ * (in registers across the transitions of one serial_advance()); in memory the stack pointer is
+ * current between calls of serial_advance(), the phase of a frame while it is not on top */
+__device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict__ sh, int &sp, int &phase)
 {
     const int ML = sh.par.ML;
     {
-        if (sh.sp < 0) {
-            if (!band_advance(F, sh)) { sh.op = OP_DONE; return 0; }
+        if (sp < 0) {
+            sh.sp = sp;
+            const int more = band_advance(F, sh);        /* may push the root of the next band */
+            sp = sh.sp; phase = sp >= 0 ? sh.st[sp].phase : 0;
+            if (!more) { sh.op = OP_DONE; return 0; }
             if (sh.op == OP_CHROMA) return 0;
             return 1;
         }
-        SFrame &fr = sh.st[sh.sp];
+        SFrame &fr = sh.st[sp];
 #if defined(FC_PM) && FC_PM == 4
         /* developer micro-benchmark of the serial lane under the live load of the CU: every 1024th
          * transition, 64 dependent LDS reads / 64 dependent float adds / 64 independent LDS reads /
@@ -2091,15 +2093,15 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
         }
 #endif
 #if defined(FC_PM) && FC_PM == 3
-        { unsigned long long t_ = wall_clock64(); sh.pm[sh.pm_prev & 7] += t_ - sh.pm_t; sh.pm_t = t_; sh.pm_prev = fr.phase; }
+        { unsigned long long t_ = wall_clock64(); sh.pm[sh.pm_prev & 7] += t_ - sh.pm_t; sh.pm_t = t_; sh.pm_prev = phase; }
 #endif
 #ifdef FC_SERIAL_PROFILE
         {   /* developer profile: ticks per phase of the state machine (previous phase ends here) */
             unsigned long long t = wall_clock64();
-            sh.tk_ph[sh.ph_prev] += t - sh.ph_t0; sh.ph_t0 = t; sh.ph_prev = fr.phase;
+            sh.tk_ph[sh.ph_prev] += t - sh.ph_t0; sh.ph_t0 = t; sh.ph_prev = phase;
         }
 #endif
-        switch (fr.phase) {
+        switch (phase) {
         case PH_ENTER: {
             Range &rg = fr.rg;
             rg.into[0] = NOEDGE;
@@ -2120,7 +2122,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             fr.pred_done = 0;
             fr.norm_first = 1; fr.norm_done = 0;     /* clear_norms_table, folded into the first update */
 #endif
-            fr.phase = PH_AFTER_INIT;
+            phase = PH_AFTER_INIT;
             if (rg.level == sh.par.lc_max) {
                 rg.address = rg.image = 0;
                 sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
@@ -2144,16 +2146,16 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             fr.coop = !fr.leaf && rg.level <= sh.par.lc_max;
             if (!fr.leaf && !fr.coop) {
                 fr.pool0 = sh.pool;
-                snap_save(F, sh, sh.sp, 0);
-                tm_save(sh, sh.sp, ML);
+                snap_save(F, sh, sp, 0);
+                tm_save(sh, sp, ML);
 #if FC_VARIANT_BIG
-                if (sh.nslot == 5 && !fr.delta) { fr.dpool0 = sh.dpool; snap_save_d(sh, sh.sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) { fr.dpool0 = sh.dpool; snap_save_d(sh, sp, 2); }
 #endif
             }
             fr.states = sh.states;
             for (int l = 0; l < 2; l++)                 /* codec/subdivide.c:167-173 */
                 fr.ny[l] = (sh.band && fr.y_state != RANGE_) ? (int) TREE(F, fr.y_state, l) : RANGE_;
-            fr.phase = PH_AFTER_LC;
+            phase = PH_AFTER_LC;
             if (rg.level <= sh.par.lc_max) {
                 fr.lrange = rg;
                 fr.lrange.tree = RANGE_;
@@ -2177,15 +2179,15 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             Range &rg = fr.rg;
             if (fr.leaf) {
                 fr.subdiv = MAXCOSTS;
-                fr.phase = PH_DECIDE;
+                phase = PH_DECIDE;
                 break;
             }
             if (!fr.coop) {
 #if FC_VARIANT_BIG
                 fr.pool_lc = sh.pool;
-                snap_save(F, sh, sh.sp, 1);
+                snap_save(F, sh, sp, 1);
                 sh.pool = fr.pool0;
-                snap_load(F, sh, sh.sp, 0);
+                snap_load(F, sh, sp, 0);
 #else
                 /* a node above the largest block level: no linear combination has touched the
                  * models since the snapshot of its entry */
@@ -2227,10 +2229,10 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 fr.subdiv = (fr.rrange.tree_bits + fr.rrange.weights_bits + fr.rrange.matrix_bits) * fr.price;
 #endif
                 fr.label = 0;
-                fr.phase = PH_CHILD;
+                phase = PH_CHILD;
             } else {
                 fr.subdiv = MAXCOSTS;
-                fr.phase = PH_DECIDE;
+                phase = PH_DECIDE;
             }
             break;
         }
@@ -2243,7 +2245,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             ch.level = rr.level - 1;
             ch.x = (rr.level & 1) ? rr.x : rr.x + label * (int) width_of_level(rr.level - 1);
             ch.y = (rr.level & 1) ? rr.y + label * (int) height_of_level(rr.level - 1) : rr.y;
-            fr.phase = PH_CHILD2;
+            phase = PH_CHILD2;
             if (label && rr.level <= sh.par.lc_max && sh.states > fr.states && !sh.band) {
                 sh.op = OP_IPIS_INCR; sh.a0 = ch.image; sh.a1 = ch.address; sh.a2 = ch.level;
                 sh.a3 = fr.states;
@@ -2254,11 +2256,11 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
         case PH_CHILD2: {
             float lim = fr.lincomb > fr.max_costs ? fr.max_costs : fr.lincomb;
             float remaining = lim - fr.subdiv;
-            fr.phase = PH_CHILD_RET;
+            phase = PH_CHILD_RET;
             fr.ret = 0;
             if (remaining > 0) {
-                if (sh.sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
-                SFrame &cf = sh.st[sh.sp + 1];
+                if (sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; break; }
+                SFrame &cf = sh.st[sp + 1];
                 cf.rg = fr.child[fr.label];
                 cf.y_state = fr.ny[fr.label];
                 cf.max_costs = remaining;
@@ -2266,7 +2268,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
 #if FC_VARIANT_BIG
                 cf.pred = fr.pred; cf.delta = fr.delta;
 #endif
-                sh.sp++;
+                fr.phase = phase; sp++; phase = PH_ENTER;   /* this frame rests: its phase goes to memory */
                 break;                              /* child result arrives in fr.ret */
             }
             fr.ret = -1;                            /* marker: no recursion happened */
@@ -2291,7 +2293,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             if (fr.ret >= 0) fr.subdiv += fr.ret;
             if (fr.subdiv >= lim) {
                 fr.subdiv = MAXCOSTS;
-                fr.phase = PH_DECIDE;
+                phase = PH_DECIDE;
                 break;
             }
             const Range &ch = fr.child[label];
@@ -2311,13 +2313,13 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             tree_update_dev(sh, ML, 1, ch.level, 1);
 #endif
             fr.label = label + 1;
-            fr.phase = fr.label < 2 ? PH_CHILD : PH_DECIDE;
+            phase = fr.label < 2 ? PH_CHILD : PH_DECIDE;
             break;
         }
         case PH_DECIDE: {
             Range &rg = fr.rg;
 #if FC_VARIANT_BIG
-            if (fr.try_pred && !fr.pred_done && !sh.failed) { fr.phase = PH_PRED_BEGIN; break; }
+            if (fr.try_pred && !fr.pred_done && !sh.failed) { phase = PH_PRED_BEGIN; break; }
 #endif
             if (fr.leaf) {                       /* models are already what they have to be */
                 if (fr.lincomb < MAXCOSTS) { rg = fr.lrange; fr.ret = fr.lincomb; }
@@ -2325,10 +2327,10 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 goto pop;
             } else if (fr.lincomb >= MAXCOSTS && fr.subdiv >= MAXCOSTS) {
                 sh.pool = fr.pool0;
-                snap_load(F, sh, sh.sp, 0);
-                tm_load(sh, sh.sp, ML);
+                snap_load(F, sh, sp, 0);
+                tm_load(sh, sp, ML);
 #if FC_VARIANT_BIG
-                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sh.sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2); }
 #endif
                 sh.states = fr.states;
                 if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
@@ -2336,11 +2338,11 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 goto pop;
             } else if (fr.lincomb < fr.subdiv) {
                 sh.pool = fr.pool_lc;
-                snap_load(F, sh, sh.sp, 1);
-                tm_load(sh, sh.sp, ML);
+                snap_load(F, sh, sp, 1);
+                tm_load(sh, sp, ML);
 #if FC_VARIANT_BIG
                 /* the linear combination left the resting models as they were at the entry */
-                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sh.sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2); }
 #endif
                 rg = fr.lrange;
                 sh.states = fr.states;
@@ -2357,7 +2359,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
 #endif
                 if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
                 store_new_state(F, sh, fr, aux);
-                fr.phase = PH_AFTER_APPEND;
+                phase = PH_AFTER_APPEND;
                 if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return 0; }
                 break;
             }
@@ -2380,16 +2382,16 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             fr.rec_states = sh.states;
             /* what the recursion left behind */
             fr.pool_rec = sh.pool; fr.dpool_rec = sh.dpool;
-            snap_save(F, sh, sh.sp, 3); snap_save_d(sh, sh.sp, 4); tm_save(sh, sh.sp, ML, 1);
+            snap_save(F, sh, sp, 3); snap_save_d(sh, sp, 4); tm_save(sh, sp, ML, 1);
             /* back to the models of the entry */
             sh.pool = fr.pool0; sh.dpool = fr.dpool0;
-            snap_load(F, sh, sh.sp, 0); snap_load_d(sh, sh.sp, 2); tm_load(sh, sh.sp, ML, 0);
+            snap_load(F, sh, sp, 0); snap_load_d(sh, sp, 2); tm_load(sh, sp, ML, 0);
             sh.states = fr.states;
             if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
             if (fr.try_pred == 2) {          /* mc_prediction, prediction.c:262-289 */
                 sh.op = OP_MC_SEARCH; sh.a0 = rg.level; sh.a1 = rg.x | (rg.y << 16);
                 sh.a2 = (rg.level == F.p_min ? 1 : 0) | (rg.level > F.p_min && fr.norm_first ? 2 : 0);
-                fr.phase = PH_PRED_MC2;
+                phase = PH_PRED_MC2;
                 return 0;
             }
             {   /* the range's DC part in the DC format of the normal model */
@@ -2403,7 +2405,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 fr.nd_wbits = (float) (0.0 - log2((double) (cnt / (float) sh.cb.tot[0])));
             }
             fr.pred_costs = fr.price * (fr.nd_wbits + fr.nd_tbits);
-            fr.phase = PH_PRED_GO;
+            phase = PH_PRED_GO;
             break;
         }
         case PH_PRED_MC2: {                  /* find_P_frame_mc done: vector in sh.mc (prediction.c:282-289) */
@@ -2413,28 +2415,28 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             fr.prange.mv_tree_bits = sh.mc.tree_bits; fr.prange.mv_coord_bits = sh.mc.bits;
             fr.nd_tbits = sh.mc.tree_bits; fr.nd_wbits = sh.mc.bits;      /* mvt, mvc kept for PH_PRED_DONE */
             fr.pred_costs = (fr.prange.mv_tree_bits + fr.prange.mv_coord_bits) * fr.price;
-            fr.phase = PH_PRED_GO;
+            phase = PH_PRED_GO;
             break;
         }
         case PH_PRED_GO: {
             if (fr.pred_costs < fr.pred_max) {
-                if (fr.rec_states - fr.states > F.max_save || sh.sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; }
+                if (fr.rec_states - fr.states > F.max_save || sp + 1 >= FC_DEPTH) { sh.failed = FC_ERR_INTERNAL; }
                 else {
                     sh.op = OP_PRED_SETUP; sh.a0 = fr.rg.level; sh.a1 = fr.rg.address;
-                    fr.phase = PH_PRED_RECURSE;
+                    phase = PH_PRED_RECURSE;
                     return 0;
                 }
             }
             /* no residual search: everything back as the recursion left it */
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
-            snap_load(F, sh, sh.sp, 3); snap_load_d(sh, sh.sp, 4); tm_load(sh, sh.sp, ML, 1);
+            snap_load(F, sh, sp, 3); snap_load_d(sh, sp, 4); tm_load(sh, sp, ML, 1);
             sh.states = fr.rec_states;
             fr.rg.prediction = 0;
-            fr.phase = PH_DECIDE;
+            phase = PH_DECIDE;
             break;
         }
         case PH_PRED_RECURSE: {              /* subdivide (max_costs - costs, ..., NO, YES), :432-456 */
-            SFrame &cf = sh.st[sh.sp + 1];
+            SFrame &cf = sh.st[sp + 1];
             cf.rg = fr.rg;
             if (fr.try_pred == 2) for (int i = 0; i < 5; i++) cf.rg.mv[i] = fr.prange.mv[i];
             cf.rg.tree_bits = cf.rg.matrix_bits = cf.rg.weights_bits = 0;
@@ -2445,7 +2447,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             cf.phase = PH_ENTER;
             cf.pred = 0; cf.delta = 1;
             fr.phase = PH_PRED_RET;
-            sh.sp++;
+            sp++; phase = PH_ENTER;
             break;
         }
         case PH_PRED_RET: {
@@ -2454,7 +2456,7 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             const int keep = !sh.failed && costs < fr.pred_max && (fr.try_pred == 2 || fr.prange.tree != RANGE_);
             fr.pred_costs = costs;
             sh.op = OP_PRED_FINISH; sh.a0 = keep;
-            fr.phase = PH_PRED_DONE;
+            phase = PH_PRED_DONE;
             fr.label = keep;                 /* remembered for PH_PRED_DONE */
             return 0;
         }
@@ -2479,22 +2481,22 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
                 goto pop;
             }
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
-            snap_load(F, sh, sh.sp, 3); snap_load_d(sh, sh.sp, 4); tm_load(sh, sh.sp, ML, 1);
+            snap_load(F, sh, sp, 3); snap_load_d(sh, sp, 4); tm_load(sh, sp, ML, 1);
             sh.states = fr.rec_states;
             {   /* columns of ids the residual search used are stale in older rows */
                 const int lim = fr.states & ~(GRAM_FB - 1);
                 if (sh.flim > lim) sh.flim = lim;
             }
             rg.prediction = 0;
-            fr.phase = PH_DECIDE;
+            phase = PH_DECIDE;
             break;
         }
 #endif
         }
         return 1;
     pop:
-        if (sh.sp > 0) {
-            SFrame &pf = sh.st[sh.sp - 1];
+        if (sp > 0) {
+            SFrame &pf = sh.st[sp - 1];
 #if FC_VARIANT_BIG
             if (pf.phase == PH_PRED_RET) pf.prange = fr.rg;
             else
@@ -2502,7 +2504,8 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
             pf.child[pf.label] = fr.rg;
             pf.ret = fr.ret;
         }
-        sh.sp--;
+        sp--;
+        if (sp >= 0) phase = sh.st[sp].phase;
     }
     return 1;
 }
@@ -2510,13 +2513,32 @@ __device__ __noinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restrict
 /* advance the partition search until a data-parallel operation is required */
 #if FC_SERIAL_LOOP
 __device__ __noinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
-#else
-__device__ __forceinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
-#endif
 {
-    while (serial_step(F, sh))
+    int sp = sh.sp, phase = sp >= 0 ? sh.st[sp].phase : 0;
+    while (serial_step(F, sh, sp, phase))
+        ;
+    sh.sp = sp;
+    if (sp >= 0) sh.st[sp].phase = phase;
+}
+#else
+/* One transition per out-of-line call on purpose (builds with machine LICM): as a loop inside one
+ * function the compiler hoists every constant and LDS address of every phase into registers for the
+ * whole loop, ~120 VGPRs, and the function then saves and restores 48 callee-saved registers
+ * through scratch memory on every call. */
+__device__ __noinline__ int serial_step_call(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    int sp = sh.sp, phase = sp >= 0 ? sh.st[sp].phase : 0;
+    const int r = serial_step(F, sh, sp, phase);
+    sh.sp = sp;
+    if (sp >= 0) sh.st[sp].phase = phase;
+    return r;
+}
+__device__ __forceinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    while (serial_step_call(F, sh))
         ;
 }
+#endif
 
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
 __device__ void basis_init(DevFrame &F, Sh &sh)

@@ -17,7 +17,12 @@ lib.set_verbosity(0)
 if max(w, h) > 2048:
     lib.set_limits(30000, 26)
 opt = lib.cli_options()
-uniq = [synth.pgm_bytes(synth.synth(w, h, 1234 if i == 0 else 1000 + i)) for i in range(nd)]
+if os.environ.get("PROBE_COLOR"):          # colour frames (Y, Cb, Cr bands): SURVEY Appendix C k-generator
+    if max(w, h) > 1280:
+        lib.set_limits(30000, 26)              # 1080p colour needs the limits extension
+    uniq = [synth.ppm_bytes(synth.synth_color_k(w, h, 1234 if i == 0 else 1000 + i)) for i in range(nd)]
+else:
+    uniq = [synth.pgm_bytes(synth.synth(w, h, 1234 if i == 0 else 1000 + i)) for i in range(nd)]
 frames = [uniq[i % nd] for i in range(n)]
 t0 = time.time()
 batch = fiasco_amd.Batch(lib, frames, 20.0, opt)

@@ -61,7 +61,11 @@ class Stats(ctypes.Structure):
                 ("t_mpB", ctypes.c_ulonglong), ("n_blockevals", ctypes.c_ulonglong),
                 ("dbg", ctypes.c_ulonglong * 8), ("states_sum", ctypes.c_ulonglong),
                 ("states_max", ctypes.c_ulonglong), ("reencodes", ctypes.c_ulonglong),
-                ("frames_by_build", ctypes.c_ulonglong * 5)]
+                ("frames_by_build", ctypes.c_ulonglong * 5),
+                ("spec_frames", ctypes.c_ulonglong), ("spec_tasks", ctypes.c_ulonglong),
+                ("spec_confirmed", ctypes.c_ulonglong), ("spec_wrong", ctypes.c_ulonglong),
+                ("spec_timeout", ctypes.c_ulonglong), ("spec_inline", ctypes.c_ulonglong),
+                ("spec_wait", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):

@@ -34,6 +34,12 @@ extern "C" void fc_launch_wide_tri(DevFrame *d_frames, unsigned n, unsigned nlen
 extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 
+/* block-level speculation (frame_coder.h, FcSpecCtl): n frames with G workgroups each */
+extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
+extern "C" unsigned fc_spec_slot_bytes(void);
+extern "C" unsigned fc_spec_ctl_bytes(void);
+extern "C" int fc_occupancy_spec(void);
+
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
  * second-domain retry */
@@ -504,6 +510,8 @@ struct FrameSlot {
     bool     wide_only = false;  /* default geometry, but beyond the 256-thread build's LDS pools */
     bool     tri = false;        /* triangular Gram tables (half the slab; the wide_tri build of the kernel) */
     bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
+    bool     spec = false;       /* several workgroups per frame (FC_SPEC build): the slab's capacity holds the
+                                  * verifiers' state-id ranges */
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
     const int16_t *ext_next = nullptr;   /* ... of the frames the NEXT pass encodes */
@@ -567,7 +575,33 @@ struct Staged {
     unsigned *d_queue = nullptr;   /* two counters per kernel build: tickets taken, slabs handed back */
     unsigned *d_ptrmask = nullptr;
     bool      ptrmask_ready = false;
+    /* block-level speculation: workgroups per frame (0 = off), the descriptors of the verifier
+     * workgroups, and one buffer with -- per frame -- control block + checkpoint slots, then the
+     * verifiers' private tables */
+    int       specG = 0;
+    DevFrame *d_vframes = nullptr;
+    size_t    vframes_n = 0;
+    char     *d_spec = nullptr;
+    size_t    d_spec_bytes = 0, spec_ctl_span = 0;
+    std::vector<size_t> spec_frames;       /* batch positions of the speculating frames of the launch in flight */
 };
+
+/* A launch that leaves workgroup slots of the chip free gives its frames several workgroups each
+ * (frame_coder.h, FcSpecCtl).  Which frames: gray intra frames of the default geometry whose state
+ * capacity -- with room for the verifiers' id ranges -- still fits the 256-thread build.
+ * FIASCO_AMD_SPEC=0 switches it off, FIASCO_AMD_SPEC=<G> asks for G workgroups per frame. */
+static int spec_groups(size_t frames, int cus)
+{
+    const char *e = getenv("FIASCO_AMD_SPEC");
+    if (e && atoi(e) <= 1) return 0;
+    if (getenv("FIASCO_AMD_TRACE") || getenv("FIASCO_AMD_NO_WIDE") || getenv("FIASCO_AMD_FORCE_TRI")) return 0;
+    int occ = fc_occupancy_spec();
+    if (occ < 1) occ = 1;
+    size_t G = frames ? (size_t) cus * (size_t) occ / frames : 0;
+    if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
+    if (e && (size_t) atoi(e) < G) G = (size_t) atoi(e);
+    return G >= 2 ? (int) G : 0;
+}
 
 static inline const fa_image *slot_image(const Staged *S, const FrameSlot &fs)
 {
@@ -696,7 +730,7 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
     /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
-    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !getenv("FIASCO_AMD_NO_QUEUE");
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !getenv("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
@@ -837,6 +871,8 @@ extern "C" void fa_core_unstage(void *h)
     if (S->d_ring) (void) hipFree(S->d_ring);
     if (S->d_queue) (void) hipFree(S->d_queue);
     if (S->d_ptrmask) (void) hipFree(S->d_ptrmask);
+    if (S->d_vframes) (void) hipFree(S->d_vframes);
+    if (S->d_spec) (void) hipFree(S->d_spec);
     if (S->cstream) { (void) hipStreamSynchronize(S->cstream); (void) hipStreamDestroy(S->cstream); }
     for (int i = 0; i < 2; i++) if (S->d_pack[i]) (void) hipFree(S->d_pack[i]);
     if (S->pinned) (void) hipHostFree(S->pinned);
@@ -863,6 +899,14 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         return S;
     }
     log2_patch_build();                      /* once per process and device */
+    int specG = 0;
+    {
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        specG = spec_groups(n, ncu);
+        S->specG = specG;
+    }
     if (hipStreamCreate(&S->stream) != hipSuccess || hipEventCreate(&S->ev0) != hipSuccess
         || hipEventCreate(&S->ev1) != hipSuccess
         || hipMalloc((void **) &S->d_frames, sizeof(DevFrame) * (n ? n : 1)) != hipSuccess) {
@@ -888,6 +932,10 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.P = (int) align_up(guess, 64);
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
+        if (specG && !fs.big && !fs.wide_only && !jobs[i].image->color && !jobs[i].ycol_carry) {
+            const size_t withids = align_up(guess + (size_t) (specG - 1) * FC_SPEC_TEMPS, 64);
+            if (withids <= 12 * 256 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
+        }
         /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
         if (!fs.big && getenv("FIASCO_AMD_FORCE_TRI")) fs.tri = true;
         /* colour: the two chroma bands add auxiliary states (no tables) */
@@ -951,7 +999,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                 size_t blocks = (size_t) ((job->image->width + bw - 1) / bw) * ((job->image->height + bh - 1) / bh);
                 size_t tight = align_up(blocks + blocks * 3 / 20 + 64, 64);
                 if (tight > cp->limit_states) tight = align_up(cp->limit_states, 64);
-                if ((size_t) fs.P <= tight) continue;
+                if ((size_t) fs.P <= tight || fs.spec) continue;
                 const size_t cap = align_up(cp->limit_states, 64);
                 fs.P = (int) tight;
                 fs.PA = job->image->color ? (int) (3 * tight > cap ? cap : 3 * tight) : fs.P;
@@ -1222,7 +1270,7 @@ static bool launch_wave(Staged *S)
      * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[5] = { 0, 0, 0, 0, 0 }, group_lend[5] = { 0, 0, 0, 0, 0 }, group_borrow[5] = { 0, 0, 0, 0, 0 };
+    size_t group_n[6] = { 0, 0, 0, 0, 0, 0 }, group_lend[6] = { 0, 0, 0, 0, 0, 0 }, group_borrow[6] = { 0, 0, 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1232,18 +1280,20 @@ static bool launch_wave(Staged *S)
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
-        for (int g = 0; g < 5; g++)
+        for (int g = 0; g < 6; g++)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
-                    if ((fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
+                    /* group 5: several workgroups per frame (FC_SPEC build) */
+                    const bool spec = fs.spec && S->specG >= 2 && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 256;
+                    if ((spec ? 5 : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
                     ordered.push_back(batch[b]);
                     group_n[g]++;
-                    g_stats.frames_by_build[g]++;
+                    if (g < 5) g_stats.frames_by_build[g]++; else g_stats.spec_frames++;
                     if (part == 0) group_lend[g]++; else if (part == 1) group_borrow[g]++;
                 }
         batch.swap(ordered);
@@ -1285,7 +1335,73 @@ static bool launch_wave(Staged *S)
     if (trace_path && hipMalloc((void **) &S->d_trace, sizeof(FcTrace) * trace_cap) == hipSuccess) {
         hf[0].trace = S->d_trace; hf[0].trace_cap = trace_cap;
     }
-    bool fail = hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
+    bool fail = false;
+    S->spec_frames.clear();
+    if (group_n[5]) {
+        /* the frames of group 5 (they are the last of the batch): control block + checkpoint slots per
+         * frame, then per verifier workgroup its private <sub-block, state> tables, scan scratch and
+         * pool list; verifier r of a frame owns the state ids [P - 16 r, P - 16 (r - 1)) */
+        const int G = S->specG;
+        const size_t n5 = group_n[5], first5 = batch.size() - n5;
+        const size_t span = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * fc_spec_slot_bytes(), 256);
+        std::vector<size_t> priv(n5);
+        size_t need = span * n5;
+        for (size_t i = 0; i < n5; i++) {
+            const DevFrame &F = hf[first5 + i];
+            const size_t P = (size_t) F.P;
+            priv[i] = align_up((size_t) F.NS * P * 4, 256) + align_up((size_t) F.NS * (P / 64) * 4, 256)
+                      + align_up((size_t) F.NA * P * 4, 256) + 3 * align_up(P * 4, 256) + align_up((size_t) FC_MAXED * P * 4, 256)
+                      + align_up(P, 256) + align_up((P + 8) * 2, 256) + align_up(((size_t) F.PA + 8) * 4, 256);
+            need += priv[i] * (size_t) (G - 1);
+        }
+        if (need > S->d_spec_bytes) {
+            if (S->d_spec) (void) hipFree(S->d_spec);
+            S->d_spec = nullptr; S->d_spec_bytes = 0;
+            if (hipMalloc((void **) &S->d_spec, need) == hipSuccess) S->d_spec_bytes = need; else (void) hipGetLastError();
+        }
+        if (n5 * (size_t) (G - 1) > S->vframes_n) {
+            if (S->d_vframes) (void) hipFree(S->d_vframes);
+            S->d_vframes = nullptr; S->vframes_n = 0;
+            if (hipMalloc((void **) &S->d_vframes, sizeof(DevFrame) * n5 * (size_t) (G - 1)) == hipSuccess) S->vframes_n = n5 * (size_t) (G - 1);
+            else (void) hipGetLastError();
+        }
+        S->spec_ctl_span = span;
+        if (S->d_spec && S->d_vframes) {
+            std::vector<DevFrame> vf(n5 * (size_t) (G - 1));
+            size_t o = span * n5;
+            for (size_t i = 0; i < n5; i++) {
+                DevFrame &C = hf[first5 + i];
+                C.spec = (FcSpecCtl *) (S->d_spec + span * i);
+                C.spec_role = 0; C.spec_G = G;
+                C.spec_cap = C.P - (G - 1) * FC_SPEC_TEMPS;
+                C.spec_tb = C.P;
+                for (int r = 1; r < G; r++) {
+                    DevFrame &V = vf[i * (size_t) (G - 1) + (size_t) (r - 1)];
+                    V = C;
+                    V.spec_role = r; V.spec_tb = C.P - r * FC_SPEC_TEMPS;
+                    const size_t P = (size_t) C.P;
+                    char *q = S->d_spec + o;
+                    V.ipis = (float *) q;  q += align_up((size_t) C.NS * P * 4, 256);
+                    V.cmax = (float *) q;  q += align_up((size_t) C.NS * (P / 64) * 4, 256);
+                    V.d5 = (float *) q;    q += align_up((size_t) C.NA * P * 4, 256);
+                    V.num = (float *) q;   q += align_up(P * 4, 256);
+                    V.den = (float *) q;   q += align_up(P * 4, 256);
+                    V.est = (float *) q;   q += align_up(P * 4, 256);
+                    V.ipdo = (float *) q;  q += align_up((size_t) FC_MAXED * P * 4, 256);
+                    V.used = (uint8_t *) q; q += align_up(P, 256);
+                    V.pool_states = (int16_t *) q; q += align_up((P + 8) * 2, 256);
+                    V.hits = (int *) q;    q += align_up(((size_t) C.PA + 8) * 4, 256);
+                    V.trace = nullptr; V.trace_cap = 0; V.pack_dst = nullptr;
+                    o += priv[i];
+                }
+                S->spec_frames.push_back(first5 + i);
+            }
+            fail = fail || hipMemsetAsync(S->d_spec, 0, span * n5, S->stream) != hipSuccess;
+            fail = fail || hipMemcpy(S->d_vframes, vf.data(), sizeof(DevFrame) * vf.size(), hipMemcpyHostToDevice) != hipSuccess;
+        } else
+            for (size_t i = 0; i < n5; i++) hf[first5 + i].spec = nullptr;      /* no memory: one workgroup per frame */
+    }
+    fail = fail || hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
                                hipMemcpyHostToDevice, S->stream) != hipSuccess;
     /* ---- one persistent launch per kernel build: one workgroup per frame ---- */
     fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
@@ -1297,6 +1413,12 @@ static bool launch_wave(Staged *S)
         if (getenv("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(getenv("FIASCO_AMD_QUEUE_WAIT_MS"));
         static const launch_fn launch[5] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri };
         size_t first = 0;
+        if (group_n[5] && !fail) {
+            const size_t first5 = batch.size() - group_n[5];
+            /* without the verifiers' buffers: G = 1, the chain alone */
+            const bool on = S->d_spec && S->d_vframes && !S->spec_frames.empty();
+            fc_launch_spec(S->d_frames + first5, S->d_vframes, (unsigned) group_n[5], on ? (unsigned) S->specG : 1u, S->stream);
+        }
         for (int g = 0; g < 5 && !fail; g++) {
             size_t plain = group_n[g], at = first;
             if (group_borrow[g]) {
@@ -1343,6 +1465,17 @@ static void complete_wave(Staged *S)
         }
         fail = hipMemcpy(hf.data(), S->d_frames, sizeof(DevFrame) * batch.size(),
                          hipMemcpyDeviceToHost) != hipSuccess;
+    }
+    if (!fail && !S->spec_frames.empty() && S->d_spec) {
+        std::vector<FcSpecCtl> ctl(S->spec_frames.size());
+        if (hipMemcpy2D(ctl.data(), sizeof(FcSpecCtl), S->d_spec, S->spec_ctl_span, sizeof(FcSpecCtl), ctl.size(),
+                        hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t i = 0; i < ctl.size(); i++) {
+                g_stats.spec_tasks += ctl[i].n_tasks; g_stats.spec_confirmed += ctl[i].n_confirmed;
+                g_stats.spec_wrong += ctl[i].n_wrong; g_stats.spec_timeout += ctl[i].n_timeout;
+                g_stats.spec_inline += ctl[i].n_inline; g_stats.spec_wait += ctl[i].t_wait;
+            }
+        else (void) hipGetLastError();
     }
     const char *trace_path = getenv("FIASCO_AMD_TRACE");
     if (S->d_trace && !fail && trace_path) {
@@ -1426,6 +1559,7 @@ static void complete_wave(Staged *S)
             fs.P = (int) (np > cap ? cap : np);
             fs.PA = (int) (npa > cap ? cap : npa);
             if (fs.PA < fs.P) fs.PA = fs.P;
+            if (fs.P > 12 * 256) fs.spec = false;      /* beyond the 256-thread build: one (wide) workgroup */
             if (!stage_slot(S, fs)) fs.done = true;
             continue;
         }

@@ -155,9 +155,47 @@ typedef struct DevFrame {
      * re-bases the slab pointers of the frame's descriptor onto its own slab. ---- */
     char    *slab_base;
     unsigned long long slab_bytes;
+    /* ---- block-level speculation (FC_SPEC build of the kernel, see FcSpecCtl below): the frame is
+     * served by spec_G workgroups that share its slab -- role 0 runs the partition search and
+     * speculates, the others verify.  spec == null: one workgroup, no speculation. ---- */
+    struct FcSpecCtl *spec;
+    int      spec_role, spec_G;
+    int      spec_tb;      /* verifier: first of the FC_SPEC_TEMPS state ids it may use for the states its
+                            * subtree search appends (all tables of the slab, private index range) */
+    int      spec_cap;     /* chain: state capacity left of the verifiers' index ranges */
 } DevFrame;
 
 #define FC_DESC_WORDS ((sizeof(DevFrame) + 7) / 8)      /* 8-byte words of a descriptor */
+
+/*
+ *  Block-level speculation.  At the CLI's geometry nine of ten blocks of the largest block level end
+ *  as ONE linear combination, and everything the partition search does below such a block (20 of
+ *  its 21 matching-pursuit calls on average) leaves no trace: models, tree model and state count go
+ *  back to what the combination left (codec/subdivide.c:431-459).  The chain workgroup therefore
+ *  runs only the combination of a block, assumes that it wins, and goes on to the next block; the
+ *  complete search of the block -- from the SAME entry state, with the same code -- is done by a
+ *  verifier workgroup in parallel.  Its verdict is exact: "the combination wins" confirms what the
+ *  chain assumed, anything else takes the chain back to the checkpoint of that block, which it
+ *  then searches itself.  The bytes of the stream cannot depend on any of this.
+ *
+ *  Per frame, in HBM: this control block, then FC_SPEC_W checkpoint slots of sizeof(Sh) bytes (the
+ *  complete LDS state of the chain at the entry of a block: input of the verifier, and what the
+ *  chain returns to after a wrong guess).
+ */
+#define FC_SPEC_W      16       /* checkpoints / verifications in flight per frame */
+#define FC_SPEC_TEMPS  16       /* state ids per verifier: a block has 2 + 4 + 8 inner nodes below its root */
+#define FC_SPEC_MAXG   8        /* workgroups per frame: chain + 7 verifiers */
+typedef struct FcSpecCtl {
+    unsigned next;              /* verifiers: next sequence number to take */
+    unsigned epoch;             /* bumped by the chain whenever it goes back: verifications in flight are void */
+    unsigned done;              /* the chain has finished the frame */
+    unsigned slot_bytes;        /* size of a checkpoint slot */
+    unsigned slot_seq[FC_SPEC_W];   /* seq + 1 once the checkpoint of block `seq` is complete, 0 while written */
+    unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 2 | code: 1 the combination wins, 2 anything else */
+    /* statistics (chain) */
+    unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
+    unsigned long long pad[2];
+} FcSpecCtl;
 
 /* automaton row of one state, as store_state_data keeps it */
 typedef struct FcSavedRow {

@@ -93,6 +93,10 @@
 #define FC_LAUNCH    fc_launch_wide
 #define FC_OCCUPANCY fc_occupancy_wide
 #endif
+#elif defined(FC_SPEC) && FC_SPEC
+#define FC_KERNEL    fiasco_frame_kernel_spec
+#define FC_LAUNCH    fc_launch_spec
+#define FC_OCCUPANCY fc_occupancy_spec
 #else
 #define FC_KERNEL    fiasco_frame_kernel
 #define FC_LAUNCH    fc_launch
@@ -105,6 +109,16 @@
  * i.e. at most 128 VGPRs and 40 KB of LDS per frame */
 #define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 4)
 #endif
+#endif
+/* FC_SPEC: block-level speculation (frame_coder.h, FcSpecCtl): a frame is served by several
+ * workgroups that share its slab -- the 256-thread default build with the chain / verifier roles.
+ * A build of its own so that the code of the launches that fill the chip with frames (one
+ * workgroup per frame, no spare workgroup slots to speculate with) stays what it is. */
+#ifndef FC_SPEC
+#define FC_SPEC 0
+#endif
+#if FC_SPEC && (FC_VARIANT_BIG || FC_VARIANT_WIDE || (defined(FC_GRAM_TRI) && FC_GRAM_TRI))
+#error "FC_SPEC is a variant of the 256-thread default build"
 #endif
 /* FC_SCAN_SL: the matching-pursuit scan recomputes a candidate from its table rows in every pass
  * (mp_sl.inc) instead of carrying it through the call in registers (mp_reg.inc) */
@@ -134,7 +148,7 @@
 #define MIN_NORM 2e-3f
 
 enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA,
-       OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH };
+       OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH, OP_SPEC_CKPT, OP_SPEC_ROLLBACK };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
        PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO };
 enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
@@ -174,6 +188,9 @@ struct __attribute__((aligned(16))) SFrame {
     float max_costs, lincomb, subdiv, ret, price;
     int   label, states, phase, leaf, coop;
     int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
+#if FC_SPEC
+    int   ckpt;                  /* a checkpoint of the workgroup was taken at the entry of this node */
+#endif
 #if FC_VARIANT_BIG
     /* prediction (codec/prediction.c:96-208): `pred` / `delta` are the arguments of the same name
      * of subdivide(); the rec_* members are what predict_range keeps of the subdivision result */
@@ -294,7 +311,7 @@ struct Sh {
 #endif
     float    pixels[FC_PIXELS];
     float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
-    unsigned long long tk[12];     /* ticks per op (lane 0) */
+    unsigned long long tk[16];     /* ticks per op (lane 0) */
     struct {
         unsigned long long bytes_mp, bytes_img, bytes_gram, n_mp, n_steps, n_blocks, n_appends,
                            n_fulleval, n_blockevals, t_mpA, t_mpB;
@@ -335,7 +352,35 @@ struct Sh {
     int      states;               /* wfa->states */
     int      flim;                 /* Gram tables: states below it have mirrored entries */
     int      failed;
+#if FC_SPEC
+    /* A verifier sees the states the frame had at the entry of its block, [0, gap_lo), and the
+     * states its own search appends, which get ids from gap_hi on (a private index range of every
+     * table of the shared slab); the ids in between belong to the chain, which is ahead and still
+     * writes them: nothing may look at them.  Chain: gap_lo == gap_hi == 0. */
+    int      gap_lo, gap_hi;
+    unsigned deadmask;             /* scan slots (B candidates each) that lie inside the gap */
+    int      cap;                  /* state ids of this workgroup end here (FC_ERR_CAPACITY) */
+    struct SpecLocal {
+        FcSpecCtl *ctl;
+        char     *slots;           /* FC_SPEC_W checkpoints of sizeof(Sh) bytes */
+        int       role, on;        /* 0 chain, 1.. verifier; on: the frame speculates at all */
+        int       floor;           /* verifier: stack depth of the block it verifies */
+        unsigned  head, commit;    /* chain: checkpoints published / verdicts consumed */
+        unsigned  spec_mask;       /* chain: per slot, the block's subtree was left to its verifier */
+        int       nospec;          /* chain: the block being entered is searched here (wrong guess before) */
+        unsigned  epoch;           /* chain: its count of returns; verifier: the epoch of its task */
+        int       verdict, abort;  /* verifier */
+        unsigned  ops;
+        float     thr;             /* chain: costs of a combination above which the block is searched here */
+        unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
+    } sl;
+#endif
 };
+#if FC_SPEC
+#define DEAD(sh, s) ((unsigned) ((int) (s) - (sh).gap_lo) < (unsigned) ((sh).gap_hi - (sh).gap_lo))
+#else
+#define DEAD(sh, s) false
+#endif
 
 /* ------------------------------------------------------------------ small helpers */
 
@@ -501,6 +546,9 @@ __device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, 
 {
     const int tid = threadIdx.x, P = F.P;
     int flim = sh.flim;
+#if FC_SPEC
+    if (sh.sl.role > 0) return;      /* a verifier reads what its own states have in their own rows */
+#endif
     if (upto - flim < GRAM_FB) return;                      /* uniform */
     __syncthreads();                                        /* the rows are complete */
     while (upto - flim >= GRAM_FB) {
@@ -733,7 +781,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
             const EdgeRows cur = nx;
             const bool valid = s < states;
             if (s + B < states) load_edge_rows(T, s + B, nx);
-            const bool tabled = valid && cur.dt;
+            const bool tabled = valid && cur.dt && !DEAD(sh, s);
             if (!bounds && !tabled) continue;
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
@@ -825,7 +873,7 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
     const int tid = threadIdx.x, P = F.P;
     float *const D5 = ACT_D5(F, sh);
     for (int s = from + tid; s < to; s += B) {
-        if (!F.domain_type[s]) continue;
+        if (DEAD(sh, s) || !F.domain_type[s]) continue;
         float v[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) v[k] = F.imgT[(size_t) k * P + s];
@@ -1013,7 +1061,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             float vt[32];
 #pragma unroll
             for (int k = 0; k < 32; k++) vt[k] = ldg(imgT, (unsigned) (k * Pu + t));
-            if (!rows.dt) continue;
+            if (!rows.dt || DEAD(sh, t)) continue;
             /* term lists of t in registers (fixed slots: 0 = tree child, 1.. = edges), loaded
              * once and reused by every table level */
             int   i2[2][FC_MAXE + 1];
@@ -1975,6 +2023,9 @@ __device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_s
     r.max_costs = MAXCOSTS;
     r.y_state = y_state;
     r.phase = PH_ENTER;
+#if FC_SPEC
+    r.ckpt = 0;
+#endif
 #if FC_VARIANT_BIG
     r.rg.nd_tree_bits = r.rg.nd_weights_bits = r.rg.mv_tree_bits = r.rg.mv_coord_bits = 0; r.rg.prediction = 0;
     for (int i = 0; i < 5; i++) r.rg.mv[i] = 0;
@@ -2024,6 +2075,40 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
     return 1;
 }
 
+#if FC_SPEC
+#define SPEC_TIMEOUT_TICKS 20000000ull      /* 0.2 s of the 100 MHz wall clock: then the chain does the block itself */
+/* Chain, lane 0: consume the verdicts that have arrived, in block order.  `drain`: wait for all of
+ * them (end of the frame); otherwise wait only while every checkpoint slot is taken.  Returns 1 when
+ * the chain has to go back to a checkpoint (sh.op / sh.a0 say which). */
+__device__ int spec_poll(Sh &sh, bool drain)
+{
+    Sh::SpecLocal &sl = sh.sl;
+    FcSpecCtl *c = sl.ctl;
+    unsigned long long t0 = 0;
+    while (sl.commit != sl.head) {
+        const unsigned slot = sl.commit % FC_SPEC_W;
+        const bool mine = (sl.spec_mask >> slot) & 1u;
+        if (!mine) { sl.commit++; t0 = 0; continue; }     /* searched here anyway: whatever the verifier says */
+        const unsigned v = __hip_atomic_load(&c->verdict[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 2) != sl.commit + 1) {                   /* not there yet */
+            if (!drain && sl.head - sl.commit < FC_SPEC_W) return 0;
+            const unsigned long long now = wall_clock64();
+            if (!t0) t0 = now;
+            if (now - t0 < SPEC_TIMEOUT_TICKS) { __builtin_amdgcn_s_sleep(16); continue; }
+            sl.t_wait += now - t0;
+            sl.n_timeout++;                                /* no verifier in sight: the chain is not held up by it */
+        } else {
+            if (t0) { sl.t_wait += wall_clock64() - t0; t0 = 0; }
+            if ((v & 3u) == 1u) { sl.commit++; sl.n_confirmed++; continue; }
+            sl.n_wrong++;
+        }
+        sh.op = OP_SPEC_ROLLBACK; sh.a0 = (int) slot;
+        return 1;
+    }
+    return 0;
+}
+#endif
+
 /* One transition of the state machine per call; 1 = call again, 0 = sh.op holds the next parallel
  * operation (or OP_DONE).  One transition per call on purpose: as a loop inside one function the
  * compiler hoists every constant and LDS address of every phase into registers for the whole
@@ -2039,6 +2124,12 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 {
     const int ML = sh.par.ML;
     {
+#if FC_SPEC
+        if (sh.sl.role > 0 && sp < sh.sl.floor) {        /* not reached: a verifier ends in PH_DECIDE of its block */
+            sh.sl.verdict = 2; sh.op = OP_DONE; return 0;
+        }
+        if (sp < 0 && sh.sl.on && spec_poll(sh, true)) { sh.sp = sp; return 0; }     /* a wrong guess: back */
+#endif
         if (sp < 0) {
             sh.sp = sp;
             const int more = band_advance(F, sh);        /* may push the root of the next band */
@@ -2109,6 +2200,14 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             fr.ret = MAXCOSTS;
             if (sh.failed || rg.level < 3) { fr.ret = MAXCOSTS; goto pop; }
             if (rg.x >= sh.par.width || rg.y >= sh.par.height) { fr.ret = 0; goto pop; }
+#if FC_SPEC
+            /* entry of a block of the largest block level: verdicts that have arrived, then the
+             * checkpoint of this block (OP_SPEC_CKPT; the node is entered again afterwards) */
+            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band && !fr.ckpt) {
+                if (spec_poll(sh, false)) return 0;
+                if (!sh.sl.nospec && rg.level > sh.lc_min) { fr.ckpt = 1; sh.op = OP_SPEC_CKPT; return 0; }
+            }
+#endif
             fr.price = sh.par.price;
             if (sh.band) fr.price *= sh.par.chroma_decrease;
 #if FC_VARIANT_BIG
@@ -2194,6 +2293,21 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 fr.pool_lc = sh.pool;
 #endif
             }
+#if FC_SPEC
+            if (sh.sl.role == 0 && fr.ckpt && rg.level == sh.par.lc_max) {
+                const unsigned slot = (sh.sl.head - 1) % FC_SPEC_W;      /* this block's checkpoint */
+                if (sh.sl.nospec) {
+                    sh.sl.nospec = 0;            /* back from a wrong guess: this block is searched here */
+                    sh.sl.n_inline++;
+                } else if (fr.lincomb < sh.sl.thr && !sh.failed) {
+                    /* the guess: the combination wins.  Its verifier searches the block. */
+                    sh.sl.spec_mask |= 1u << slot;
+                    fr.subdiv = MAXCOSTS;
+                    phase = PH_DECIDE;
+                    break;
+                } else sh.sl.n_inline++;
+            }
+#endif
             if (rg.level > sh.lc_min) {
                 Range z;
                 z.x = z.y = z.image = z.address = z.level = 0; z.tree = 0;
@@ -2265,6 +2379,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 cf.y_state = fr.ny[fr.label];
                 cf.max_costs = remaining;
                 cf.phase = PH_ENTER;
+#if FC_SPEC
+                cf.ckpt = 0;
+#endif
 #if FC_VARIANT_BIG
                 cf.pred = fr.pred; cf.delta = fr.delta;
 #endif
@@ -2318,6 +2435,15 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
         }
         case PH_DECIDE: {
             Range &rg = fr.rg;
+#if FC_SPEC
+            if (sh.sl.role > 0 && sp == sh.sl.floor) {
+                /* the verifier's block: all the chain needs to know is whether the combination wins
+                 * (the branch `lincomb < subdiv` below) */
+                sh.sl.verdict = (!sh.failed && !fr.leaf && fr.lincomb < MAXCOSTS && fr.lincomb < fr.subdiv) ? 1 : 2;
+                sh.op = OP_DONE;
+                return 0;
+            }
+#endif
 #if FC_VARIANT_BIG
             if (fr.try_pred && !fr.pred_done && !sh.failed) { phase = PH_PRED_BEGIN; break; }
 #endif
@@ -2357,7 +2483,11 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                  * tables (codec/subdivide.c:571-583,607; the constant pool takes every state) */
                 if (F.pred_on && sh.pool.n >= sh.pool.max_domains) aux = 1;
 #endif
+#if FC_SPEC
+                if (sh.states >= (sh.band ? sh.par.PA : sh.cap)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+#else
                 if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+#endif
                 store_new_state(F, sh, fr, aux);
                 phase = PH_AFTER_APPEND;
                 if (!aux) { sh.op = OP_APPEND; sh.a0 = sh.states; return 0; }
@@ -2366,7 +2496,11 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
         }
         case PH_AFTER_APPEND: {
             sh.states++;
+#if FC_SPEC
+            if (sh.states - (sh.gap_hi - sh.gap_lo) >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
+#else
             if (sh.states >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
+#endif
             fr.rg = fr.rrange;
             fr.ret = fr.subdiv;
             goto pop;
@@ -2585,14 +2719,36 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
  *  slab it got.  No tail of idle CUs waiting for the slowest of the first frames, no limit on the
  *  size of a launch from the 200 MB slabs.
  */
+#if FC_SPEC
+#define SPEC_STRIDE ((unsigned) ((sizeof(Sh) + 255) / 256 * 256))          /* bytes per checkpoint slot */
+#define SPEC_SLOTS(ctl) ((char *) (ctl) + (sizeof(FcSpecCtl) + 255) / 256 * 256)
+#endif
+
 __global__ void __launch_bounds__(B, FC_WG_PER_CU)
+#if FC_SPEC
+/* G workgroups per frame: workgroup f * G is the chain of frame f (descriptor frames[f]), the G - 1
+ * after it are its verifiers (descriptors vframes[f * (G - 1) ..]: the chain's with private
+ * <sub-block, state> tables, scratch and state-id range).  G == 1: no speculation. */
+FC_KERNEL(DevFrame *frames, DevFrame *vframes, unsigned G)
+#else
 FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask,
           unsigned long long queue_wait_ticks)
+#endif
 {
     __shared__ Sh sh;
+#if FC_SPEC
+    __shared__ Sh::SpecLocal sl_keep;
+    __shared__ unsigned task_seq;
+    __shared__ int task_go;
+    const unsigned role = blockIdx.x % G;
+    DevFrame &F = role ? vframes[(blockIdx.x / G) * (G - 1) + role - 1] : frames[blockIdx.x / G];
+    unsigned long long *const ring = nullptr;
+#else
     DevFrame &F = frames[blockIdx.x];
+#endif
     const int tid = threadIdx.x;
 
+#if !FC_SPEC
     if (ring && blockIdx.x >= nlend) {
         /* a frame without a slab: wait for the next free one and move the descriptor onto it */
         __shared__ unsigned long long got;
@@ -2637,7 +2793,22 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();                    /* the descriptor is read through the scalar cache */
     }
+#endif
 
+#if FC_SPEC
+    if (tid == 0) {
+        Sh::SpecLocal &sl = sh.sl;
+        sh.gap_lo = sh.gap_hi = 0; sh.deadmask = 0;
+        sh.cap = F.spec ? F.spec_cap : F.P;
+        sl.ctl = F.spec; sl.slots = F.spec ? SPEC_SLOTS(F.spec) : nullptr;
+        sl.role = (int) role; sl.on = F.spec != nullptr && G > 1;
+        sl.floor = 0; sl.head = sl.commit = 0; sl.spec_mask = 0; sl.nospec = 0; sl.epoch = 0;
+        sl.verdict = 0; sl.abort = 0; sl.ops = 0; sl.thr = MAXCOSTS;
+        sl.n_tasks = sl.n_confirmed = sl.n_wrong = sl.n_timeout = sl.n_inline = sl.t_wait = 0;
+        sl_keep = sl;
+    }
+    if (role == 0) {
+#endif
     if (tid < 10 && tid >= 1)
         sh.m0tab[tid] = (float) -log2((double) (1 - 1 / (float) (1 << tid)));
     if (tid == 0) {
@@ -2784,9 +2955,12 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     }
     if (F.color)                              /* calloc'ed in the reference (codec/wfa.h) */
         for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = F.ycol0 ? F.ycol0[i] : (uint8_t) 0;
+#if FC_SPEC
+    }
+#endif
     /* per-op tick counters live in LDS: a private array indexed by `op` would be scratch */
     unsigned long long *tk = sh.tk;
-    if (tid == 0) for (int k = 0; k < 12; k++) tk[k] = 0;
+    if (tid == 0) for (int k = 0; k < 16; k++) tk[k] = 0;
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { for (int k = 0; k < 8; k++) sh.tk_ph[k] = 0; sh.ph_prev = 0; sh.ph_t0 = 0; sh.tk_init[0] = sh.tk_init[1] = 0; for (int k = 0; k < 4; k++) sh.tk_apx[k] = 0; }
 #endif
@@ -2797,12 +2971,95 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     /* everything below is inlined into this one loop (a single call site per op keeps the
      * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
      * table accesses are global_load, not flat_load through a generic reference) */
+#if FC_SPEC
+    for (;;) {          /* chain: once.  Verifier: once per block it verifies, until the chain is done. */
+    if (role) {
+        FcSpecCtl *const c = F.spec;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(&c->next, 1u);
+            int go = 1;
+            for (;;) {
+                if (__hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == t + 1) break;
+                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            task_seq = t; task_go = go;
+        }
+        __syncthreads();
+        if (!task_go) break;                                      /* uniform */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        /* nothing stale in this CU's L1 */
+        {   /* the chain's LDS state at the entry of the block */
+            const uint4 *src = (const uint4 *) (SPEC_SLOTS(c) + (size_t) (task_seq % FC_SPEC_W) * SPEC_STRIDE);
+            for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned task_epoch = sh.sl.epoch;              /* the chain's, as of the checkpoint */
+            /* the slot was not taken for a later block while it was read, and the chain has not gone
+             * back behind this block since */
+            bool valid = __hip_atomic_load(&c->slot_seq[task_seq % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == task_seq + 1
+                         && __hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == task_epoch;
+            sh.sl = sl_keep;
+            sh.sl.epoch = task_epoch;
+            const int S0 = sh.states, TB = F.spec_tb;
+            if (valid && (S0 > TB || sh.sp < 0 || sh.sp >= FC_DEPTH)) valid = false;
+            sh.sl.floor = sh.sp; sh.sl.verdict = 2; sh.sl.abort = valid ? 0 : 1; sh.sl.ops = 0;
+            sh.gap_lo = S0; sh.gap_hi = TB; sh.states = TB; sh.cap = TB + FC_SPEC_TEMPS;
+            unsigned dm = 0;
+            for (int k = 0; k < 32; k++) if (k * B >= S0 && (k + 1) * B <= TB) dm |= 1u << k;
+            sh.deadmask = dm;
+            sh.par.ipis = F.ipis; sh.par.at_pool = F.pool_states;   /* private: block tables, pool list */
+            sh.par.trace_on = 0;
+            sh.op = valid ? OP_NOP : OP_DONE;
+        }
+    }
+#endif
     for (;;) {
         __syncthreads();
         const int op = sh.op;
         if (op == OP_DONE) break;
         unsigned long long t0 = wall_clock64();
         switch (op) {
+#if FC_SPEC
+        case OP_SPEC_CKPT: {
+            /* the complete LDS state of the chain at the entry of a block: what a verifier starts
+             * from, and what the chain returns to if its guess about the block is wrong */
+            FcSpecCtl *const c = sh.sl.ctl;
+            const unsigned seq = sh.sl.head, slot = seq % FC_SPEC_W;
+            if (tid == 0) __hip_atomic_store(&c->slot_seq[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __syncthreads();
+            uint4 *dst = (uint4 *) (sh.sl.slots + (size_t) slot * SPEC_STRIDE);
+            for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) dst[i] = ((const uint4 *) &sh)[i];
+            __threadfence();                 /* + every table row written so far */
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
+            }
+            break;
+        }
+        case OP_SPEC_ROLLBACK: {
+            FcSpecCtl *const c = sh.sl.ctl;
+            const unsigned slot = (unsigned) sh.a0;
+            if (tid == 0) sl_keep = sh.sl;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            const uint4 *src = (const uint4 *) (sl_keep.slots + (size_t) slot * SPEC_STRIDE);
+            for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
+            __syncthreads();
+            if (tid == 0) {
+                sh.sl = sl_keep;
+                sh.sl.nospec = 1;                     /* this block is searched here */
+                sh.sl.commit = sh.sl.head;            /* every verification in flight is void ... */
+                sh.sl.epoch++;                        /* ... and its verifier should drop it */
+                __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+#endif
         case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1); break;
         case OP_APPROX:     op_approx(F, sh); break;
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
@@ -2817,6 +3074,12 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         default: break;                      /* OP_NOP */
         }
         __syncthreads();
+#if FC_SPEC
+        if (tid == 0 && role && (++sh.sl.ops & 7u) == 0
+            && __hip_atomic_load(&F.spec->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh.sl.epoch) {
+            sh.sl.abort = 1; sh.op = OP_DONE;         /* the chain has gone back behind this block */
+        } else
+#endif
         if (tid == 0) {                       /* partition search, lane 0 */
             unsigned long long t1 = wall_clock64();
             tk[op] += t1 - t0;
@@ -2836,6 +3099,23 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             tk[0] += wall_clock64() - t1;
         }
     }
+#if FC_SPEC
+    if (!role) break;
+    __syncthreads();
+    if (tid == 0 && !sh.sl.abort)
+        __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W], ((task_seq + 1) << 2) | (unsigned) sh.sl.verdict,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (role) return;
+    if (tid == 0 && sh.sl.on) {
+        FcSpecCtl *const c = sh.sl.ctl;
+        /* verifiers that are still at a block the chain went back behind drop it; the others leave */
+        __hip_atomic_store(&c->epoch, sh.sl.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        c->n_tasks = sh.sl.n_tasks; c->n_confirmed = sh.sl.n_confirmed; c->n_wrong = sh.sl.n_wrong;
+        c->n_timeout = sh.sl.n_timeout; c->n_inline = sh.sl.n_inline; c->t_wait = sh.sl.t_wait;
+    }
+#endif
     if (tid == 0) {
         F.t_serial = tk[0]; F.t_init = tk[OP_INIT_RANGE]; F.t_approx = tk[OP_APPROX];
         F.t_ipis = tk[OP_IPIS_INCR]; F.t_append = tk[OP_APPEND];
@@ -2866,6 +3146,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         const unsigned n16 = F.pack_bytes / 16;
         for (unsigned i = tid; i < n16; i += B) dst[i] = src[i];
     }
+#if !FC_SPEC
     if (ring) {                               /* the slab is free for the next frame without one */
         __threadfence();
         __syncthreads();
@@ -2874,6 +3155,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             __hip_atomic_store(&ring[i], (unsigned long long) F.slab_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#endif
 }
 
 /* workgroups of this build a CU holds at once: what the build was compiled for (its launch bound
@@ -2886,8 +3168,19 @@ extern "C" int FC_OCCUPANCY(void)
     return by_lds < FC_WG_PER_CU ? (by_lds < 1 ? 1 : by_lds) : FC_WG_PER_CU;
 }
 
+#if FC_SPEC
+/* n frames, G workgroups each (all n * G must be resident at once: a chain whose verifiers are not
+ * does their blocks itself after a bounded wait, see spec_poll) */
+extern "C" void FC_LAUNCH(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream)
+{
+    hipLaunchKernelGGL(FC_KERNEL, dim3(n * G), dim3(B), 0, stream, d_frames, d_vframes, G);
+}
+extern "C" unsigned fc_spec_slot_bytes(void) { return SPEC_STRIDE; }
+extern "C" unsigned fc_spec_ctl_bytes(void) { return (unsigned) ((sizeof(FcSpecCtl) + 255) / 256 * 256); }
+#else
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                           const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream)
 {
     hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask, queue_wait_ticks);
 }
+#endif

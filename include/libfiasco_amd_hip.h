@@ -36,6 +36,11 @@ typedef struct fiasco_amd_stats {
     /* frames launched per kernel build: default 256 / 1024 threads, big 256 / 512 threads, default
      * 1024 threads with triangular Gram tables */
     unsigned long long frames_by_build[5];
+    /* block-level speculation (several workgroups per frame, launches that leave workgroup slots of
+     * the chip free): frames encoded that way, blocks whose subtree search was handed to a verifier
+     * workgroup, verdicts that confirmed / contradicted the chain's guess, verifications given up
+     * after a bounded wait, blocks the chain searched itself, ticks (100 MHz) it waited for verdicts */
+    unsigned long long spec_frames, spec_tasks, spec_confirmed, spec_wrong, spec_timeout, spec_inline, spec_wait;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

@@ -65,7 +65,8 @@ class Stats(ctypes.Structure):
                 ("spec_frames", ctypes.c_ulonglong), ("spec_tasks", ctypes.c_ulonglong),
                 ("spec_confirmed", ctypes.c_ulonglong), ("spec_wrong", ctypes.c_ulonglong),
                 ("spec_timeout", ctypes.c_ulonglong), ("spec_inline", ctypes.c_ulonglong),
-                ("spec_wait", ctypes.c_ulonglong)]
+                ("spec_wait", ctypes.c_ulonglong), ("spec_tab_used", ctypes.c_ulonglong),
+                ("spec_tab_missed", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):

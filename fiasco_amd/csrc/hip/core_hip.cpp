@@ -590,6 +590,36 @@ struct Staged {
  * (frame_coder.h, FcSpecCtl).  Which frames: gray intra frames of the default geometry whose state
  * capacity -- with room for the verifiers' id ranges -- still fits the 256-thread build.
  * FIASCO_AMD_SPEC=0 switches it off, FIASCO_AMD_SPEC=<G> asks for G workgroups per frame. */
+/* of the G workgroups of a frame: the chain, T table workers, G - 1 - T verifiers */
+static int spec_workers(int G)
+{
+    const char *e = getenv("FIASCO_AMD_SPEC_T");           /* experiments */
+    if (e && atoi(e) >= 0 && atoi(e) < G - 1) return atoi(e);
+    return G >= 6 ? 2 : G >= 4 ? 1 : 0;
+}
+
+/* the blocks of the largest block level in the order the partition search visits them
+ * (codec/subdivide.c:277-290: the children of a node, first label first; invisible ranges are skipped, :118-120) */
+static void spec_block_list(const DevFrame &F, std::vector<uint16_t> &out)
+{
+    struct Node { int level, x, y; };
+    std::vector<Node> stack;
+    stack.push_back(Node{F.level, 0, 0});
+    out.clear();
+    while (!stack.empty()) {
+        const Node n = stack.back();
+        stack.pop_back();
+        if (n.x >= F.width || n.y >= F.height) continue;
+        if (n.level == F.lc_max) { out.push_back((uint16_t) n.x); out.push_back((uint16_t) n.y); continue; }
+        if (n.level < F.lc_max) continue;
+        const int l1 = n.level - 1;
+        const int w1 = 1 << (l1 >> 1), h1 = 1 << ((l1 + 1) >> 1);
+        /* second child first onto the stack: the first is visited first */
+        if (n.level & 1) { stack.push_back(Node{l1, n.x, n.y + h1}); stack.push_back(Node{l1, n.x, n.y}); }
+        else             { stack.push_back(Node{l1, n.x + w1, n.y}); stack.push_back(Node{l1, n.x, n.y}); }
+    }
+}
+
 static int spec_groups(size_t frames, int cus)
 {
     const char *e = getenv("FIASCO_AMD_SPEC");
@@ -597,10 +627,20 @@ static int spec_groups(size_t frames, int cus)
     if (getenv("FIASCO_AMD_TRACE") || getenv("FIASCO_AMD_NO_WIDE") || getenv("FIASCO_AMD_FORCE_TRI")) return 0;
     int occ = fc_occupancy_spec();
     if (occ < 1) occ = 1;
-    size_t G = frames ? (size_t) cus * (size_t) occ / frames : 0;
+    if (!frames) return 0;
+    if (e) {                                  /* as asked, if the chip holds that many workgroups at once */
+        size_t G = (size_t) cus * (size_t) occ / frames;
+        if ((size_t) atoi(e) < G) G = (size_t) atoi(e);
+        if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
+        return G >= 2 ? (int) G : 0;
+    }
+    /* by default only while every workgroup has a CU to itself (measured, 1080p: 1 frame 1.8 x, 16
+     * frames 1.6 x the rate of one wide workgroup per frame; with two workgroups per CU the verifiers
+     * take from the chains what they give, with four the launch is slower) and with at least three
+     * verifiers per chain (one or two keep it waiting) */
+    size_t G = (size_t) cus / frames;
     if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
-    if (e && (size_t) atoi(e) < G) G = (size_t) atoi(e);
-    return G >= 2 ? (int) G : 0;
+    return G >= 4 ? (int) G : 0;
 }
 
 static inline const fa_image *slot_image(const Staged *S, const FrameSlot &fs)
@@ -933,7 +973,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
         if (specG && !fs.big && !fs.wide_only && !jobs[i].image->color && !jobs[i].ycol_carry) {
-            const size_t withids = align_up(guess + (size_t) (specG - 1) * FC_SPEC_TEMPS, 64);
+            const size_t withids = align_up(guess + (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS, 64);
             if (withids <= 12 * 256 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
         }
         /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
@@ -1343,7 +1383,21 @@ static bool launch_wave(Staged *S)
          * pool list; verifier r of a frame owns the state ids [P - 16 r, P - 16 (r - 1)) */
         const int G = S->specG;
         const size_t n5 = group_n[5], first5 = batch.size() - n5;
-        const size_t span = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * fc_spec_slot_bytes(), 256);
+        const int T = spec_workers(G), NV = G - 1 - T;           /* table workers, verifiers */
+        /* control block, checkpoint slots, block list, table ring -- the same span for every frame of
+         * the launch (sized for the largest) */
+        size_t max_blocks = 0, max_tab = 0;
+        std::vector<std::vector<uint16_t>> lists(n5);
+        for (size_t i = 0; i < n5; i++) {
+            const DevFrame &F = hf[first5 + i];
+            spec_block_list(F, lists[i]);
+            if (lists[i].size() / 2 > max_blocks) max_blocks = lists[i].size() / 2;
+            const size_t tab = align_up(((size_t) F.NS + (size_t) F.NA) * (size_t) F.P * 4, 256);
+            if (tab > max_tab) max_tab = tab;
+        }
+        const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * fc_spec_slot_bytes(), 256);
+        const size_t off_tabs = align_up(off_blocks + max_blocks * 4, 256);
+        const size_t span = align_up(off_tabs + (T ? (size_t) FC_SPEC_R * max_tab : 0), 256);
         std::vector<size_t> priv(n5);
         size_t need = span * n5;
         for (size_t i = 0; i < n5; i++) {
@@ -1352,7 +1406,7 @@ static bool launch_wave(Staged *S)
             priv[i] = align_up((size_t) F.NS * P * 4, 256) + align_up((size_t) F.NS * (P / 64) * 4, 256)
                       + align_up((size_t) F.NA * P * 4, 256) + 3 * align_up(P * 4, 256) + align_up((size_t) FC_MAXED * P * 4, 256)
                       + align_up(P, 256) + align_up((P + 8) * 2, 256) + align_up(((size_t) F.PA + 8) * 4, 256);
-            need += priv[i] * (size_t) (G - 1);
+            need += priv[i] * (size_t) NV;
         }
         if (need > S->d_spec_bytes) {
             if (S->d_spec) (void) hipFree(S->d_spec);
@@ -1372,13 +1426,18 @@ static bool launch_wave(Staged *S)
             for (size_t i = 0; i < n5; i++) {
                 DevFrame &C = hf[first5 + i];
                 C.spec = (FcSpecCtl *) (S->d_spec + span * i);
-                C.spec_role = 0; C.spec_G = G;
-                C.spec_cap = C.P - (G - 1) * FC_SPEC_TEMPS;
+                C.spec_role = 0; C.spec_G = G; C.spec_T = T;
+                C.spec_cap = C.P - NV * FC_SPEC_TEMPS;
                 C.spec_tb = C.P;
-                for (int r = 1; r < G; r++) {
+                for (int r = 1; r <= T; r++) {                   /* table workers: the chain's descriptor */
                     DevFrame &V = vf[i * (size_t) (G - 1) + (size_t) (r - 1)];
                     V = C;
-                    V.spec_role = r; V.spec_tb = C.P - r * FC_SPEC_TEMPS;
+                    V.spec_role = r; V.trace = nullptr; V.trace_cap = 0; V.pack_dst = nullptr;
+                }
+                for (int r = T + 1; r < G; r++) {
+                    DevFrame &V = vf[i * (size_t) (G - 1) + (size_t) (r - 1)];
+                    V = C;
+                    V.spec_role = r; V.spec_tb = C.P - (r - T) * FC_SPEC_TEMPS;
                     const size_t P = (size_t) C.P;
                     char *q = S->d_spec + o;
                     V.ipis = (float *) q;  q += align_up((size_t) C.NS * P * 4, 256);
@@ -1396,7 +1455,24 @@ static bool launch_wave(Staged *S)
                 }
                 S->spec_frames.push_back(first5 + i);
             }
-            fail = fail || hipMemsetAsync(S->d_spec, 0, span * n5, S->stream) != hipSuccess;
+            /* control blocks: zero, then what the host knows (sizes, offsets, the block list) */
+            for (size_t i = 0; i < n5 && !fail; i++)
+                fail = hipMemsetAsync(S->d_spec + span * i, 0, off_tabs, S->stream) != hipSuccess;
+            fail = fail || hipStreamSynchronize(S->stream) != hipSuccess;
+            for (size_t i = 0; i < n5 && !fail; i++) {
+                FcSpecCtl h;
+                memset(&h, 0, sizeof h);
+                h.slot_bytes = fc_spec_slot_bytes();
+                h.n_blocks = T ? (unsigned) (lists[i].size() / 2) : 0u;
+                h.tab_stride = (unsigned) max_tab;
+                /* 120 us: about what the chain needs to build the tables itself (tests: FIASCO_AMD_SPEC_TABWAIT=0
+                 * makes it take the worker's tables only when they are there already) */
+                h.tab_wait = getenv("FIASCO_AMD_SPEC_TABWAIT") ? (unsigned) atoi(getenv("FIASCO_AMD_SPEC_TABWAIT")) : 12000u;
+                h.off_blocks = off_blocks; h.off_tabs = off_tabs;
+                fail = hipMemcpy(S->d_spec + span * i, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess;
+                if (!fail && !lists[i].empty())
+                    fail = hipMemcpy(S->d_spec + span * i + off_blocks, lists[i].data(), lists[i].size() * 2, hipMemcpyHostToDevice) != hipSuccess;
+            }
             fail = fail || hipMemcpy(S->d_vframes, vf.data(), sizeof(DevFrame) * vf.size(), hipMemcpyHostToDevice) != hipSuccess;
         } else
             for (size_t i = 0; i < n5; i++) hf[first5 + i].spec = nullptr;      /* no memory: one workgroup per frame */
@@ -1474,6 +1550,7 @@ static void complete_wave(Staged *S)
                 g_stats.spec_tasks += ctl[i].n_tasks; g_stats.spec_confirmed += ctl[i].n_confirmed;
                 g_stats.spec_wrong += ctl[i].n_wrong; g_stats.spec_timeout += ctl[i].n_timeout;
                 g_stats.spec_inline += ctl[i].n_inline; g_stats.spec_wait += ctl[i].t_wait;
+                g_stats.spec_tab_used += ctl[i].n_tab_used; g_stats.spec_tab_missed += ctl[i].n_tab_missed;
             }
         else (void) hipGetLastError();
     }

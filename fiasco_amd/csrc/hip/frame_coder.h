@@ -163,6 +163,7 @@ typedef struct DevFrame {
     int      spec_tb;      /* verifier: first of the FC_SPEC_TEMPS state ids it may use for the states its
                             * subtree search appends (all tables of the slab, private index range) */
     int      spec_cap;     /* chain: state capacity left of the verifiers' index ranges */
+    int      spec_T;       /* workgroups 1 .. spec_T of the frame are table workers, the rest verifiers */
 } DevFrame;
 
 #define FC_DESC_WORDS ((sizeof(DevFrame) + 7) / 8)      /* 8-byte words of a descriptor */
@@ -181,10 +182,21 @@ typedef struct DevFrame {
  *  Per frame, in HBM: this control block, then FC_SPEC_W checkpoint slots of sizeof(Sh) bytes (the
  *  complete LDS state of the chain at the entry of a block: input of the verifier, and what the
  *  chain returns to after a wrong guess).
+ *
+ *  Table workers.  A third of what is left to the chain is init_range: the <sub-block, state> tables
+ *  of the next block for every state of the dictionary (codec/ip.c:72-154, codec/subdivide.c:612-644).
+ *  They are a function of the block's pixels and of the states alone -- not of the models -- and the
+ *  entries of a state depend on older states only.  Workgroups 1 .. T of the frame therefore build the
+ *  tables of the blocks AHEAD of the chain (the host lists the blocks in the order of the search),
+ *  for the states the chain has published so far, into a ring of FC_SPEC_R buffers; the chain adds
+ *  the entries of the states that have come since (and of those a return has replaced: the buffer is
+ *  tagged with the epoch it was computed in) and hands the buffer on to the block's verifier with
+ *  its checkpoint, which then needs no init_range of its own.
  */
 #define FC_SPEC_W      16       /* checkpoints / verifications in flight per frame */
 #define FC_SPEC_TEMPS  16       /* state ids per verifier: a block has 2 + 4 + 8 inner nodes below its root */
-#define FC_SPEC_MAXG   8        /* workgroups per frame: chain + 7 verifiers */
+#define FC_SPEC_MAXG   8        /* workgroups per frame: chain + table workers + verifiers */
+#define FC_SPEC_R      24       /* table buffers per frame: blocks waiting for their verdict + blocks ahead */
 typedef struct FcSpecCtl {
     unsigned next;              /* verifiers: next sequence number to take */
     unsigned epoch;             /* bumped by the chain whenever it goes back: verifications in flight are void */
@@ -194,7 +206,18 @@ typedef struct FcSpecCtl {
     unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 2 | code: 1 the combination wins, 2 anything else */
     /* statistics (chain) */
     unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
-    unsigned long long pad[2];
+    unsigned long long n_tab_used, n_tab_missed;      /* blocks whose tables came from a worker / were not there in time */
+    /* table workers */
+    unsigned s_pub;             /* states whose table rows are complete and visible (chain, at its checkpoints) */
+    unsigned tab_free;          /* blocks below this index need their table buffer no more (chain) */
+    unsigned blk_cur;           /* the block the chain is at (chain) */
+    unsigned n_blocks;          /* entries of the block list (host) */
+    unsigned tab_stride;        /* bytes per table buffer: ipis [NS][P], then d5 [NA][P] (host) */
+    unsigned tab_wait;          /* ticks (100 MHz) the chain waits for a worker's tables before it builds them itself (host) */
+    unsigned long long off_blocks, off_tabs;   /* byte offsets from this struct: block list (x, y as 2 x u16), buffers (host) */
+    unsigned tab_seq[FC_SPEC_R];    /* block index + 1 once the buffer holds that block's tables */
+    unsigned tab_s[FC_SPEC_R];      /* ... for the states below this */
+    unsigned tab_epoch[FC_SPEC_R];  /* ... read in this epoch or later */
 } FcSpecCtl;
 
 /* automaton row of one state, as store_state_data keeps it */

@@ -360,10 +360,18 @@ struct Sh {
     int      gap_lo, gap_hi;
     unsigned deadmask;             /* scan slots (B candidates each) that lie inside the gap */
     int      cap;                  /* state ids of this workgroup end here (FC_ERR_CAPACITY) */
+    int      blk;                  /* chain: blocks of the largest block level entered so far (index into the host's list) */
+    int      tab_shared;           /* the block's tables are in a buffer of the frame's ring (sh.par.ipis / d5) */
+    int      tab_from;
     struct SpecLocal {
         FcSpecCtl *ctl;
         char     *slots;           /* FC_SPEC_W checkpoints of sizeof(Sh) bytes */
-        int       role, on;        /* 0 chain, 1.. verifier; on: the frame speculates at all */
+        int       role, on;        /* 0 chain, 1 .. T table workers, then verifiers; on: the frame speculates at all */
+        int       T;
+        char     *tabs;            /* FC_SPEC_R table buffers */
+        unsigned  rb_s[32];        /* chain: state count it returned to at the end of epoch e, [e % 32] */
+        unsigned  blkof[FC_SPEC_W];    /* chain: block index of the checkpoint in a slot */
+        unsigned long long n_tab_used, n_tab_missed;
         int       floor;           /* verifier: stack depth of the block it verifies */
         unsigned  head, commit;    /* chain: checkpoints published / verdicts consumed */
         unsigned  spec_mask;       /* chain: per slot, the block's subtree was left to its verifier */
@@ -371,7 +379,12 @@ struct Sh {
         unsigned  epoch;           /* chain: its count of returns; verifier: the epoch of its task */
         int       verdict, abort;  /* verifier */
         unsigned  ops;
-        float     thr;             /* chain: costs of a combination above which the block is searched here */
+        /* chain: which blocks to guess about.  A wrong guess costs the blocks the chain ran ahead plus
+         * the search of the block; searching a block here costs that search alone.  The costs of a
+         * block's combination tell the two kinds apart fairly well: blocks whose combination costs more
+         * than SPEC_THR x the running mean over the blocks that kept theirs are searched here. */
+        float     mlc, lin[FC_SPEC_W];
+        unsigned  nlc;
         unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
     } sl;
 #endif
@@ -599,6 +612,10 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 #define ACT_IPIS(F, sh) ((sh).par.ipis)
 #define ACT_D5(F, sh)   ((sh).par.d5)
 #define ACT_D4(F, sh)   ((sh).par.d4)
+#elif FC_SPEC               /* the block's tables live in one buffer of the frame's ring, or in the workgroup's own */
+#define ACT_IPIS(F, sh) ((sh).par.ipis)
+#define ACT_D5(F, sh)   ((sh).par.d5)
+#define ACT_D4(F, sh)   ((F).d4)
 #else
 #define ACT_IPIS(F, sh) ((F).ipis)
 #define ACT_D5(F, sh)   ((F).d5)
@@ -908,7 +925,9 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
 }
 
 /* codec/subdivide.c:504-541,612-644 */
-__device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restrict__ sh, int x0, int y0)
+/* from: the entries of the states below it are in the tables already (FC_SPEC: a table worker has
+ * computed them ahead of the chain); otherwise 0 */
+__device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restrict__ sh, int x0, int y0, int from)
 {
     const int tid = threadIdx.x;
     const int level = F.lc_max, npx = 1 << level;
@@ -961,12 +980,12 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tp0 = wall_clock64();
 #endif
-    op_d5(F, sh, 0, table_states(sh), F.NA, 2 * F.NA);
+    op_d5(F, sh, from, table_states(sh), F.NA, 2 * F.NA);
     __syncthreads();
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { unsigned long long t = wall_clock64(); sh.tk_init[0] += t - tp0; tp0 = t; }
 #endif
-    op_ipis(F, sh, 0, 0, level, 0);
+    op_ipis(F, sh, 0, 0, level, from);
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) sh.tk_init[1] += wall_clock64() - tp0;
 #endif
@@ -2076,6 +2095,9 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 }
 
 #if FC_SPEC
+#ifndef SPEC_THR
+#define SPEC_THR 1.2f
+#endif
 #define SPEC_TIMEOUT_TICKS 20000000ull      /* 0.2 s of the 100 MHz wall clock: then the chain does the block itself */
 /* Chain, lane 0: consume the verdicts that have arrived, in block order.  `drain`: wait for all of
  * them (end of the frame); otherwise wait only while every checkpoint slot is taken.  Returns 1 when
@@ -2099,7 +2121,11 @@ __device__ int spec_poll(Sh &sh, bool drain)
             sl.n_timeout++;                                /* no verifier in sight: the chain is not held up by it */
         } else {
             if (t0) { sl.t_wait += wall_clock64() - t0; t0 = 0; }
-            if ((v & 3u) == 1u) { sl.commit++; sl.n_confirmed++; continue; }
+            if ((v & 3u) == 1u) {
+                sl.mlc = sl.nlc ? 0.9f * sl.mlc + 0.1f * sl.lin[slot] : sl.lin[slot]; sl.nlc++;
+                sl.commit++; sl.n_confirmed++;
+                continue;
+            }
             sl.n_wrong++;
         }
         sh.op = OP_SPEC_ROLLBACK; sh.a0 = (int) slot;
@@ -2203,9 +2229,14 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #if FC_SPEC
             /* entry of a block of the largest block level: verdicts that have arrived, then the
              * checkpoint of this block (OP_SPEC_CKPT; the node is entered again afterwards) */
-            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band && !fr.ckpt) {
+            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band) {
                 if (spec_poll(sh, false)) return 0;
-                if (!sh.sl.nospec && rg.level > sh.lc_min) { fr.ckpt = 1; sh.op = OP_SPEC_CKPT; return 0; }
+                /* table workers: where the chain is, and which buffers it needs no more (those of the
+                 * blocks below the oldest one that still waits for its verdict) */
+                FcSpecCtl *c = sh.sl.ctl;
+                const unsigned oldest = sh.sl.commit != sh.sl.head ? sh.sl.blkof[sh.sl.commit % FC_SPEC_W] : (unsigned) sh.blk;
+                __hip_atomic_store(&c->tab_free, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->blk_cur, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #endif
             fr.price = sh.par.price;
@@ -2225,12 +2256,23 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             if (rg.level == sh.par.lc_max) {
                 rg.address = rg.image = 0;
                 sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
+#if FC_SPEC
+                sh.a2 = sh.band ? -1 : sh.blk++;      /* index of the block in the host's list */
+#endif
                 return 0;
             }
             break;
         }
         case PH_AFTER_INIT: {
             Range &rg = fr.rg;
+#if FC_SPEC
+            /* a block of the largest block level, its tables done: verdicts that have arrived, then
+             * the checkpoint of this block (OP_SPEC_CKPT; the phase is entered again afterwards) */
+            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band && !fr.ckpt) {
+                if (spec_poll(sh, false)) return 0;
+                if (!sh.sl.nospec && rg.level > sh.lc_min) { fr.ckpt = 1; sh.op = OP_SPEC_CKPT; return 0; }
+            }
+#endif
             /* A range that cannot be subdivided needs no model snapshots at all: a rejected
              * linear combination leaves every model untouched (codec/approx.c:264-268), an
              * accepted one is exactly the state to continue from, and the tree model is not
@@ -2299,9 +2341,10 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 if (sh.sl.nospec) {
                     sh.sl.nospec = 0;            /* back from a wrong guess: this block is searched here */
                     sh.sl.n_inline++;
-                } else if (fr.lincomb < sh.sl.thr && !sh.failed) {
+                } else if (fr.lincomb < (sh.sl.nlc >= 8 ? SPEC_THR * sh.sl.mlc : MAXCOSTS) && !sh.failed) {
                     /* the guess: the combination wins.  Its verifier searches the block. */
                     sh.sl.spec_mask |= 1u << slot;
+                    sh.sl.lin[slot] = fr.lincomb;
                     fr.subdiv = MAXCOSTS;
                     phase = PH_DECIDE;
                     break;
@@ -2463,6 +2506,12 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 fr.ret = MAXCOSTS;
                 goto pop;
             } else if (fr.lincomb < fr.subdiv) {
+#if FC_SPEC
+                if (sh.sl.role == 0 && fr.ckpt && rg.level == sh.par.lc_max
+                    && !((sh.sl.spec_mask >> ((sh.sl.head - 1) % FC_SPEC_W)) & 1u)) {    /* searched here, kept its combination */
+                    sh.sl.mlc = sh.sl.nlc ? 0.9f * sh.sl.mlc + 0.1f * fr.lincomb : fr.lincomb; sh.sl.nlc++;
+                }
+#endif
                 sh.pool = fr.pool_lc;
                 snap_load(F, sh, sp, 1);
                 tm_load(sh, sp, ML);
@@ -2674,6 +2723,47 @@ __device__ __forceinline__ void serial_advance(DevFrame &__restrict__ F, Sh &__r
 }
 #endif
 
+#if FC_SPEC
+/* Chain, all lanes: whose tables does block `blk` get?  The buffer a table worker has filled for it
+ * (sh.tab_from = the states whose entries are good: what the worker saw, less what a return of the
+ * chain has replaced since), or -- no worker got there in time -- the chain's own tables, from scratch. */
+__device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int blk)
+{
+    if (threadIdx.x == 0) {
+        Sh::SpecLocal &sl = sh.sl;
+        FcSpecCtl *c = sl.ctl;
+        const unsigned b = (unsigned) blk % FC_SPEC_R;
+        int from = -1;
+        if ((unsigned) blk < c->n_blocks) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                if (__hip_atomic_load(&c->tab_seq[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) blk + 1) {
+                    unsigned S = __hip_atomic_load(&c->tab_s[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned te = __hip_atomic_load(&c->tab_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sl.epoch - te > 32u) S = 0;
+                    else for (unsigned e = te; e != sl.epoch; e++) if (sl.rb_s[e % 32u] < S) S = sl.rb_s[e % 32u];
+                    from = (int) S < sh.states ? (int) S : sh.states;
+                    break;
+                }
+                if (wall_clock64() - t0 > c->tab_wait) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (from >= 0) {
+            sh.par.ipis = (float *) (sl.tabs + (size_t) b * c->tab_stride);
+            sh.par.d5 = sh.par.ipis + (size_t) F.NS * F.P;
+            sh.tab_shared = 1; sl.n_tab_used++;
+        } else {
+            sh.par.ipis = F.ipis; sh.par.d5 = F.d5;
+            sh.tab_shared = 0; sl.n_tab_missed++; from = 0;
+        }
+        sh.tab_from = from;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     /* the worker's entries, not this CU's stale lines */
+}
+#endif
+
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
 __device__ void basis_init(DevFrame &F, Sh &sh)
 {
@@ -2802,8 +2892,12 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.cap = F.spec ? F.spec_cap : F.P;
         sl.ctl = F.spec; sl.slots = F.spec ? SPEC_SLOTS(F.spec) : nullptr;
         sl.role = (int) role; sl.on = F.spec != nullptr && G > 1;
+        sl.T = F.spec_T; sl.tabs = F.spec ? (char *) F.spec + F.spec->off_tabs : nullptr;
+        sl.n_tab_used = sl.n_tab_missed = 0;
+        for (int k = 0; k < 32; k++) sl.rb_s[k] = 0;
+        sh.blk = 0; sh.tab_shared = 0; sh.tab_from = 0;
         sl.floor = 0; sl.head = sl.commit = 0; sl.spec_mask = 0; sl.nospec = 0; sl.epoch = 0;
-        sl.verdict = 0; sl.abort = 0; sl.ops = 0; sl.thr = MAXCOSTS;
+        sl.verdict = 0; sl.abort = 0; sl.ops = 0; sl.mlc = 0.0f; sl.nlc = 0;
         sl.n_tasks = sl.n_confirmed = sl.n_wrong = sl.n_timeout = sl.n_inline = sl.t_wait = 0;
         sl_keep = sl;
     }
@@ -2972,6 +3066,64 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
      * kernel argument visible to the compiler: DevFrame fields come through scalar loads and
      * table accesses are global_load, not flat_load through a generic reference) */
 #if FC_SPEC
+    const unsigned T = F.spec ? (unsigned) F.spec_T : 0u;
+    if (role == 0 && F.spec && G > 1) {
+        /* the rows of the basis states are complete: table workers may start */
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&F.spec->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (role >= 1 && role <= T) {
+        /* table worker: the tables of every T-th block of the host's list, ahead of the chain, for the
+         * states the chain has published, into the buffer blk % FC_SPEC_R */
+        FcSpecCtl *const c = F.spec;
+        __shared__ int tw_x, tw_y;
+        unsigned j = role - 1;
+        const unsigned short *blocks = (const unsigned short *) ((const char *) c + c->off_blocks);
+        if (tid == 0) { sh.band = 0; sh.gap_lo = sh.gap_hi = 0; sh.deadmask = 0; sh.sl.role = (int) role; }
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) {
+                int go = 1;
+                for (;;) {
+                    if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                    const unsigned cur = __hip_atomic_load(&c->blk_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (j + 1 < cur) j += T;               /* the chain is past these (it may still wait for block cur - 1) */
+                    if (j < c->n_blocks
+                        && j < __hip_atomic_load(&c->tab_free, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + FC_SPEC_R
+                        && __hip_atomic_load(&c->s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                task_go = go;
+                if (go) {
+                    const unsigned b = j % FC_SPEC_R;
+                    __hip_atomic_store(&c->tab_seq[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    /* the epoch first: a return of the chain lowers s_pub before it raises the epoch */
+                    const unsigned e0 = __hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned S = __hip_atomic_load(&c->s_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    task_seq = e0;
+                    sh.states = (int) S;
+                    sh.par.ipis = (float *) ((char *) c + c->off_tabs + (size_t) b * c->tab_stride);
+                    sh.par.d5 = sh.par.ipis + (size_t) F.NS * F.P;
+                    tw_x = blocks[2 * j]; tw_y = blocks[2 * j + 1];
+                }
+            }
+            __syncthreads();
+            if (!task_go) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            op_init_range(F, sh, tw_x, tw_y, 0);
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned b = j % FC_SPEC_R;
+                __hip_atomic_store(&c->tab_s[b], (unsigned) sh.states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->tab_epoch[b], task_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->tab_seq[b], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                j += T;
+            }
+        }                                           /* (j is lane 0's) */
+        return;
+    }
     for (;;) {          /* chain: once.  Verifier: once per block it verifies, until the chain is done. */
     if (role) {
         FcSpecCtl *const c = F.spec;
@@ -3010,9 +3162,17 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             unsigned dm = 0;
             for (int k = 0; k < 32; k++) if (k * B >= S0 && (k + 1) * B <= TB) dm |= 1u << k;
             sh.deadmask = dm;
-            sh.par.ipis = F.ipis; sh.par.at_pool = F.pool_states;   /* private: block tables, pool list */
+            sh.par.at_pool = F.pool_states;                       /* private pool list */
             sh.par.trace_on = 0;
             sh.op = valid ? OP_NOP : OP_DONE;
+            if (valid && !sh.tab_shared) {
+                /* the chain built this block's tables in its own memory: this workgroup builds them
+                 * again in its own (otherwise they are in a buffer of the ring, complete for every
+                 * state below gap_lo, and the states appended here add their entries behind gap_hi) */
+                const Range &rg = sh.st[sh.sp].rg;
+                sh.par.ipis = F.ipis; sh.par.d5 = F.d5;
+                sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y; sh.a2 = -1;
+            }
         }
     }
 #endif
@@ -3036,8 +3196,11 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             __threadfence();                 /* + every table row written so far */
             __syncthreads();
             if (tid == 0) {
+                /* every table row of the states so far is complete and visible: table workers may use them */
+                __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
+                sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
             }
             break;
         }
@@ -3054,13 +3217,31 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                 sh.sl = sl_keep;
                 sh.sl.nospec = 1;                     /* this block is searched here */
                 sh.sl.commit = sh.sl.head;            /* every verification in flight is void ... */
+                /* the rows of the states from here on will be written again: tables computed from them
+                 * in this epoch or before count up to here only (spec_tables), and nothing beyond is
+                 * offered to the table workers until the next checkpoint */
+                sh.sl.rb_s[sh.sl.epoch % 32u] = (unsigned) sh.states;
+                __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 sh.sl.epoch++;                        /* ... and its verifier should drop it */
                 __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
+            __syncthreads();
+            /* the checkpoint was taken with the block's tables done.  In a buffer of the ring they still
+             * are; the chain's own tables have been those of later blocks since: once more */
+            if (!sh.tab_shared) op_init_range(F, sh, sh.st[sh.sp].rg.x, sh.st[sh.sp].rg.y, 0);
             break;
         }
 #endif
-        case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1); break;
+#if FC_SPEC
+        case OP_INIT_RANGE:
+            if (sh.sl.on && sh.sl.role == 0 && sh.sl.T > 0 && sh.a2 >= 0) spec_tables(F, sh, sh.a2);
+            else if (tid == 0) { sh.tab_from = 0; if (sh.sl.role == 0) { sh.par.ipis = F.ipis; sh.par.d5 = F.d5; sh.tab_shared = 0; } }
+            __syncthreads();
+            op_init_range(F, sh, sh.a0, sh.a1, sh.tab_from);
+            break;
+#else
+        case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1, 0); break;
+#endif
         case OP_APPROX:     op_approx(F, sh); break;
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
@@ -3114,6 +3295,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         __hip_atomic_store(&c->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         c->n_tasks = sh.sl.n_tasks; c->n_confirmed = sh.sl.n_confirmed; c->n_wrong = sh.sl.n_wrong;
         c->n_timeout = sh.sl.n_timeout; c->n_inline = sh.sl.n_inline; c->t_wait = sh.sl.t_wait;
+        c->n_tab_used = sh.sl.n_tab_used; c->n_tab_missed = sh.sl.n_tab_missed;
     }
 #endif
     if (tid == 0) {
@@ -3133,6 +3315,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     }
 #ifdef FC_PM
     if (tid == 0) for (int k = 0; k < 8; k++) F.dbg[k] = sh.pm[k];
+#endif
+#if FC_SPEC && !defined(FC_PM) && !defined(FC_SERIAL_PROFILE)
+    if (tid == 0) { F.dbg[0] = tk[OP_SPEC_CKPT]; F.dbg[1] = tk[OP_SPEC_ROLLBACK]; }   /* ticks of the chain in the two ops */
 #endif
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */

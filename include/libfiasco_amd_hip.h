@@ -41,6 +41,8 @@ typedef struct fiasco_amd_stats {
      * workgroup, verdicts that confirmed / contradicted the chain's guess, verifications given up
      * after a bounded wait, blocks the chain searched itself, ticks (100 MHz) it waited for verdicts */
     unsigned long long spec_frames, spec_tasks, spec_confirmed, spec_wrong, spec_timeout, spec_inline, spec_wait;
+    /* blocks whose <sub-block, state> tables a table worker had ready for the chain / had not */
+    unsigned long long spec_tab_used, spec_tab_missed;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

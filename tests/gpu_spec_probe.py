@@ -33,6 +33,12 @@ for g in gs:
               % (g, rep, dt, st.kernel_ms / 1e3, n / max(st.kernel_ms / 1e3, 1e-9), st.spec_frames, st.spec_tasks,
                  st.spec_confirmed, st.spec_wrong, st.spec_timeout, st.spec_inline, st.spec_wait / 1e8,
                  list(st.frames_by_build), md5[:3]), flush=True)
+        tt = max(st.t_total, 1)
+        print("      chain: frame %.3f s avg; init %.1f%% approx %.1f%% ipis %.1f%% append %.1f%% serial %.1f%% (of the chain's time); mp calls %d"
+              % (st.t_total / n / 1e8, 100.0 * st.t_init / tt, 100.0 * st.t_approx / tt, 100.0 * st.t_ipis / tt,
+                 100.0 * st.t_append / tt, 100.0 * st.t_serial / tt, st.n_mp // n), flush=True)
+        print("      checkpoints %.1f%% returns %.1f%% of the chain's time; tables from workers %d, missed %d"
+              % (100.0 * st.dbg[0] / tt, 100.0 * st.dbg[1] / tt, st.spec_tab_used, st.spec_tab_missed))
         if any(o is None for o in out):
             print("   ERROR:", lib.error_message())
     if ref is None:

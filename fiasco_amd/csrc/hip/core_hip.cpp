@@ -972,7 +972,10 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.P = (int) align_up(guess, 64);
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
-        if (specG && !fs.big && !fs.wide_only && !jobs[i].image->color && !jobs[i].ycol_carry) {
+        /* (colour: the luminance band; not with y_column flags carried in from an earlier frame of the
+         * stream -- the states a block search appends and removes again clear them id by id, and a
+         * verifier's ids are not the chain's) */
+        if (specG && !fs.big && !fs.wide_only && !jobs[i].ycol_carry) {
             const size_t withids = align_up(guess + (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS, 64);
             if (withids <= 12 * 256 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
         }

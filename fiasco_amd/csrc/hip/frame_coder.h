@@ -201,6 +201,7 @@ typedef struct FcSpecCtl {
     unsigned next;              /* verifiers: next sequence number to take */
     unsigned epoch;             /* bumped by the chain whenever it goes back: verifications in flight are void */
     unsigned done;              /* the chain has finished the frame */
+    unsigned busy;              /* verifiers inside a block search (the chain waits for 0 before the chroma bands re-use their state ids) */
     unsigned slot_bytes;        /* size of a checkpoint slot */
     unsigned slot_seq[FC_SPEC_W];   /* seq + 1 once the checkpoint of block `seq` is complete, 0 while written */
     unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 2 | code: 1 the combination wins, 2 anything else */

@@ -377,7 +377,7 @@ struct Sh {
         unsigned  spec_mask;       /* chain: per slot, the block's subtree was left to its verifier */
         int       nospec;          /* chain: the block being entered is searched here (wrong guess before) */
         unsigned  epoch;           /* chain: its count of returns; verifier: the epoch of its task */
-        int       verdict, abort;  /* verifier */
+        int       verdict, abort, busy;  /* verifier; busy: counted in FcSpecCtl.busy */
         unsigned  ops;
         /* chain: which blocks to guess about.  A wrong guess costs the blocks the chain ran ahead plus
          * the search of the block; searching a block here costs that search alone.  The costs of a
@@ -2155,6 +2155,20 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             sh.sl.verdict = 2; sh.op = OP_DONE; return 0;
         }
         if (sp < 0 && sh.sl.on && spec_poll(sh, true)) { sh.sp = sp; return 0; }     /* a wrong guess: back */
+        if (sp < 0 && sh.sl.on && sh.par.color && !sh.band && !sh.after_chroma) {
+            /* end of the luminance band of a colour frame: the chroma bands number their states on into
+             * the verifiers' id ranges.  No block search may start from here on (epoch), none may still
+             * be running (a verifier looks at the epoch every few operations). */
+            FcSpecCtl *c = sh.sl.ctl;
+            sh.sl.epoch++;
+            __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                if (wall_clock64() - t0 > 100000000ull) { sh.failed = FC_ERR_INTERNAL; break; }     /* 1 s */
+                __builtin_amdgcn_s_sleep(32);
+            }
+            sh.sl.on = 0;                        /* the rest of the frame is the chain's alone */
+        }
 #endif
         if (sp < 0) {
             sh.sp = sp;
@@ -3157,7 +3171,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             sh.sl.epoch = task_epoch;
             const int S0 = sh.states, TB = F.spec_tb;
             if (valid && (S0 > TB || sh.sp < 0 || sh.sp >= FC_DEPTH)) valid = false;
-            sh.sl.floor = sh.sp; sh.sl.verdict = 2; sh.sl.abort = valid ? 0 : 1; sh.sl.ops = 0;
+            sh.sl.floor = sh.sp; sh.sl.verdict = 2; sh.sl.abort = valid ? 0 : 1; sh.sl.ops = 0; sh.sl.busy = 0;
             sh.gap_lo = S0; sh.gap_hi = TB; sh.states = TB; sh.cap = TB + FC_SPEC_TEMPS;
             unsigned dm = 0;
             for (int k = 0; k < 32; k++) if (k * B >= S0 && (k + 1) * B <= TB) dm |= 1u << k;
@@ -3165,6 +3179,13 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             sh.par.at_pool = F.pool_states;                       /* private pool list */
             sh.par.trace_on = 0;
             sh.op = valid ? OP_NOP : OP_DONE;
+            if (valid) {
+                atomicAdd(&c->busy, 1u);
+                /* (the chain may have raised the epoch between the check above and this count: once more) */
+                if (__hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != task_epoch) {
+                    atomicSub(&c->busy, 1u); valid = false; sh.sl.abort = 1; sh.op = OP_DONE;
+                } else sh.sl.busy = 1;
+            }
             if (valid && !sh.tab_shared) {
                 /* the chain built this block's tables in its own memory: this workgroup builds them
                  * again in its own (otherwise they are in a buffer of the ring, complete for every
@@ -3283,12 +3304,15 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #if FC_SPEC
     if (!role) break;
     __syncthreads();
-    if (tid == 0 && !sh.sl.abort)
-        __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W], ((task_seq + 1) << 2) | (unsigned) sh.sl.verdict,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        if (!sh.sl.abort)
+            __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W], ((task_seq + 1) << 2) | (unsigned) sh.sl.verdict,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (sh.sl.busy) { __threadfence(); atomicSub(&F.spec->busy, 1u); }      /* its rows are written */
+    }
     }
     if (role) return;
-    if (tid == 0 && sh.sl.on) {
+    if (tid == 0 && sh.sl.ctl && G > 1) {
         FcSpecCtl *const c = sh.sl.ctl;
         /* verifiers that are still at a block the chain went back behind drop it; the others leave */
         __hip_atomic_store(&c->epoch, sh.sl.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -39,6 +39,8 @@ extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned
 extern "C" unsigned fc_spec_slot_bytes(void);
 extern "C" unsigned fc_spec_ctl_bytes(void);
 extern "C" int fc_occupancy_spec(void);
+extern "C" void fc_launch_spec_wide(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
+extern "C" unsigned fc_spec_slot_bytes_wide(void);
 
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
@@ -584,6 +586,7 @@ struct Staged {
     char     *d_spec = nullptr;
     size_t    d_spec_bytes = 0, spec_ctl_span = 0;
     std::vector<size_t> spec_frames;       /* batch positions of the speculating frames of the launch in flight */
+    size_t    spec_first[2] = { 0, 0 }, spec_n[2] = { 0, 0 };    /* ... per workgroup width (256, 1024 threads) */
 };
 
 /* A launch that leaves workgroup slots of the chip free gives its frames several workgroups each
@@ -975,9 +978,11 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         /* (colour: the luminance band; not with y_column flags carried in from an earlier frame of the
          * stream -- the states a block search appends and removes again clear them id by id, and a
          * verifier's ids are not the chain's) */
-        if (specG && !fs.big && !fs.wide_only && !jobs[i].ycol_carry) {
+        if (specG && !fs.big && !jobs[i].ycol_carry) {
+            /* the 256-thread build up to 3072 states, the 1024-thread one (4K; frames beyond the narrow
+             * build's LDS pools) up to 12288 */
             const size_t withids = align_up(guess + (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS, 64);
-            if (withids <= 12 * 256 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
+            if (withids <= 12 * 1024 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
         }
         /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
         if (!fs.big && getenv("FIASCO_AMD_FORCE_TRI")) fs.tri = true;
@@ -1313,7 +1318,7 @@ static bool launch_wave(Staged *S)
      * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[6] = { 0, 0, 0, 0, 0, 0 }, group_lend[6] = { 0, 0, 0, 0, 0, 0 }, group_borrow[6] = { 0, 0, 0, 0, 0, 0 };
+    size_t group_n[7] = { 0, 0, 0, 0, 0, 0, 0 }, group_lend[7] = { 0, 0, 0, 0, 0, 0, 0 }, group_borrow[7] = { 0, 0, 0, 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1323,14 +1328,15 @@ static bool launch_wave(Staged *S)
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
-        for (int g = 0; g < 6; g++)
+        for (int g = 0; g < 7; g++)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
-                    /* group 5: several workgroups per frame (FC_SPEC build) */
-                    const bool spec = fs.spec && S->specG >= 2 && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 256;
-                    if ((spec ? 5 : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
+                    /* groups 5, 6: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
+                    const bool spec = fs.spec && S->specG >= 2 && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
+                    const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only);
+                    if ((spec ? (spec_wide ? 6 : 5) : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
@@ -1380,31 +1386,36 @@ static bool launch_wave(Staged *S)
     }
     bool fail = false;
     S->spec_frames.clear();
-    if (group_n[5]) {
-        /* the frames of group 5 (they are the last of the batch): control block + checkpoint slots per
-         * frame, then per verifier workgroup its private <sub-block, state> tables, scan scratch and
-         * pool list; verifier r of a frame owns the state ids [P - 16 r, P - 16 (r - 1)) */
+    S->spec_first[0] = S->spec_first[1] = 0; S->spec_n[0] = S->spec_n[1] = 0;
+    if (group_n[5] + group_n[6]) {
+        /* the speculating frames (groups 5 and 6: 256 / 1024 threads per workgroup; they are the last of
+         * the batch): control block + checkpoint slots + block list + table ring per frame, then per
+         * verifier workgroup its private <sub-block, state> tables, scan scratch and pool list; verifier
+         * v of a frame owns the state ids [P - 16 v, P - 16 (v - 1)) */
         const int G = S->specG;
-        const size_t n5 = group_n[5], first5 = batch.size() - n5;
         const int T = spec_workers(G), NV = G - 1 - T;           /* table workers, verifiers */
-        /* control block, checkpoint slots, block list, table ring -- the same span for every frame of
-         * the launch (sized for the largest) */
-        size_t max_blocks = 0, max_tab = 0;
-        std::vector<std::vector<uint16_t>> lists(n5);
-        for (size_t i = 0; i < n5; i++) {
-            const DevFrame &F = hf[first5 + i];
+        const size_t nall = group_n[5] + group_n[6], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[5];
+        S->spec_first[1] = first_all + group_n[5]; S->spec_n[1] = group_n[6];
+        /* one span for every frame of the launch (sized for the largest) */
+        size_t max_blocks = 0, max_tab = 0, max_slot = 0;
+        std::vector<std::vector<uint16_t>> lists(nall);
+        for (size_t i = 0; i < nall; i++) {
+            const DevFrame &F = hf[first_all + i];
             spec_block_list(F, lists[i]);
             if (lists[i].size() / 2 > max_blocks) max_blocks = lists[i].size() / 2;
             const size_t tab = align_up(((size_t) F.NS + (size_t) F.NA) * (size_t) F.P * 4, 256);
             if (tab > max_tab) max_tab = tab;
+            const size_t slot = i < group_n[5] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
+            if (slot > max_slot) max_slot = slot;
         }
-        const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * fc_spec_slot_bytes(), 256);
+        const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * max_slot, 256);
         const size_t off_tabs = align_up(off_blocks + max_blocks * 4, 256);
         const size_t span = align_up(off_tabs + (T ? (size_t) FC_SPEC_R * max_tab : 0), 256);
-        std::vector<size_t> priv(n5);
-        size_t need = span * n5;
-        for (size_t i = 0; i < n5; i++) {
-            const DevFrame &F = hf[first5 + i];
+        std::vector<size_t> priv(nall);
+        size_t need = span * nall;
+        for (size_t i = 0; i < nall; i++) {
+            const DevFrame &F = hf[first_all + i];
             const size_t P = (size_t) F.P;
             priv[i] = align_up((size_t) F.NS * P * 4, 256) + align_up((size_t) F.NS * (P / 64) * 4, 256)
                       + align_up((size_t) F.NA * P * 4, 256) + 3 * align_up(P * 4, 256) + align_up((size_t) FC_MAXED * P * 4, 256)
@@ -1416,18 +1427,18 @@ static bool launch_wave(Staged *S)
             S->d_spec = nullptr; S->d_spec_bytes = 0;
             if (hipMalloc((void **) &S->d_spec, need) == hipSuccess) S->d_spec_bytes = need; else (void) hipGetLastError();
         }
-        if (n5 * (size_t) (G - 1) > S->vframes_n) {
+        if (nall * (size_t) (G - 1) > S->vframes_n) {
             if (S->d_vframes) (void) hipFree(S->d_vframes);
             S->d_vframes = nullptr; S->vframes_n = 0;
-            if (hipMalloc((void **) &S->d_vframes, sizeof(DevFrame) * n5 * (size_t) (G - 1)) == hipSuccess) S->vframes_n = n5 * (size_t) (G - 1);
+            if (hipMalloc((void **) &S->d_vframes, sizeof(DevFrame) * nall * (size_t) (G - 1)) == hipSuccess) S->vframes_n = nall * (size_t) (G - 1);
             else (void) hipGetLastError();
         }
         S->spec_ctl_span = span;
         if (S->d_spec && S->d_vframes) {
-            std::vector<DevFrame> vf(n5 * (size_t) (G - 1));
-            size_t o = span * n5;
-            for (size_t i = 0; i < n5; i++) {
-                DevFrame &C = hf[first5 + i];
+            std::vector<DevFrame> vf(nall * (size_t) (G - 1));
+            size_t o = span * nall;
+            for (size_t i = 0; i < nall; i++) {
+                DevFrame &C = hf[first_all + i];
                 C.spec = (FcSpecCtl *) (S->d_spec + span * i);
                 C.spec_role = 0; C.spec_G = G; C.spec_T = T;
                 C.spec_cap = C.P - NV * FC_SPEC_TEMPS;
@@ -1456,16 +1467,16 @@ static bool launch_wave(Staged *S)
                     V.trace = nullptr; V.trace_cap = 0; V.pack_dst = nullptr;
                     o += priv[i];
                 }
-                S->spec_frames.push_back(first5 + i);
+                S->spec_frames.push_back(first_all + i);
             }
             /* control blocks: zero, then what the host knows (sizes, offsets, the block list) */
-            for (size_t i = 0; i < n5 && !fail; i++)
+            for (size_t i = 0; i < nall && !fail; i++)
                 fail = hipMemsetAsync(S->d_spec + span * i, 0, off_tabs, S->stream) != hipSuccess;
             fail = fail || hipStreamSynchronize(S->stream) != hipSuccess;
-            for (size_t i = 0; i < n5 && !fail; i++) {
+            for (size_t i = 0; i < nall && !fail; i++) {
                 FcSpecCtl h;
                 memset(&h, 0, sizeof h);
-                h.slot_bytes = fc_spec_slot_bytes();
+                h.slot_bytes = (unsigned) max_slot;
                 h.n_blocks = T ? (unsigned) (lists[i].size() / 2) : 0u;
                 h.tab_stride = (unsigned) max_tab;
                 /* 120 us: about what the chain needs to build the tables itself (tests: FIASCO_AMD_SPEC_TABWAIT=0
@@ -1478,7 +1489,7 @@ static bool launch_wave(Staged *S)
             }
             fail = fail || hipMemcpy(S->d_vframes, vf.data(), sizeof(DevFrame) * vf.size(), hipMemcpyHostToDevice) != hipSuccess;
         } else
-            for (size_t i = 0; i < n5; i++) hf[first5 + i].spec = nullptr;      /* no memory: one workgroup per frame */
+            for (size_t i = 0; i < nall; i++) hf[first_all + i].spec = nullptr;      /* no memory: one workgroup per frame */
     }
     fail = fail || hipMemcpyAsync(S->d_frames, hf.data(), sizeof(DevFrame) * batch.size(),
                                hipMemcpyHostToDevice, S->stream) != hipSuccess;
@@ -1492,11 +1503,14 @@ static bool launch_wave(Staged *S)
         if (getenv("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(getenv("FIASCO_AMD_QUEUE_WAIT_MS"));
         static const launch_fn launch[5] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri };
         size_t first = 0;
-        if (group_n[5] && !fail) {
-            const size_t first5 = batch.size() - group_n[5];
+        for (int k = 0; k < 2 && !fail; k++) {
+            if (!S->spec_n[k]) continue;
             /* without the verifiers' buffers: G = 1, the chain alone */
             const bool on = S->d_spec && S->d_vframes && !S->spec_frames.empty();
-            fc_launch_spec(S->d_frames + first5, S->d_vframes, (unsigned) group_n[5], on ? (unsigned) S->specG : 1u, S->stream);
+            const size_t all_first = S->spec_first[0];
+            DevFrame *vfr = S->d_vframes ? S->d_vframes + (S->spec_first[k] - all_first) * (size_t) (S->specG - 1) : nullptr;
+            (k ? fc_launch_spec_wide : fc_launch_spec)(S->d_frames + S->spec_first[k], vfr, (unsigned) S->spec_n[k],
+                                                       on ? (unsigned) S->specG : 1u, S->stream);
         }
         for (int g = 0; g < 5 && !fail; g++) {
             size_t plain = group_n[g], at = first;
@@ -1639,7 +1653,7 @@ static void complete_wave(Staged *S)
             fs.P = (int) (np > cap ? cap : np);
             fs.PA = (int) (npa > cap ? cap : npa);
             if (fs.PA < fs.P) fs.PA = fs.P;
-            if (fs.P > 12 * 256) fs.spec = false;      /* beyond the 256-thread build: one (wide) workgroup */
+            if (fs.P > 12 * 1024) fs.spec = false;     /* beyond the speculating builds: one (wide) workgroup */
             if (!stage_slot(S, fs)) fs.done = true;
             continue;
         }

@@ -56,7 +56,7 @@
 #define B       FC_WIDE_B
 #if defined(FC_VARIANT_BIG) && FC_VARIANT_BIG
 #define FC_KREG 12               /* 6144 states with 4 orthogonal vectors each in registers */
-#else
+#elif !defined(FC_KREG)
 #define FC_KREG (9216 / FC_WIDE_B)
 #endif
 #else
@@ -84,7 +84,12 @@
 #define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 2)
 #else
 #if FC_VARIANT_WIDE
-#if defined(FC_GRAM_TRI) && FC_GRAM_TRI
+#if defined(FC_SPEC) && FC_SPEC
+#define FC_KERNEL    fiasco_frame_kernel_spec_wide
+#define FC_LAUNCH    fc_launch_spec_wide
+#define FC_OCCUPANCY fc_occupancy_spec_wide
+#define FC_SPEC_SLOT_BYTES fc_spec_slot_bytes_wide
+#elif defined(FC_GRAM_TRI) && FC_GRAM_TRI
 #define FC_KERNEL    fiasco_frame_kernel_wide_tri
 #define FC_LAUNCH    fc_launch_wide_tri
 #define FC_OCCUPANCY fc_occupancy_wide_tri
@@ -97,6 +102,7 @@
 #define FC_KERNEL    fiasco_frame_kernel_spec
 #define FC_LAUNCH    fc_launch_spec
 #define FC_OCCUPANCY fc_occupancy_spec
+#define FC_SPEC_SLOT_BYTES fc_spec_slot_bytes
 #else
 #define FC_KERNEL    fiasco_frame_kernel
 #define FC_LAUNCH    fc_launch
@@ -117,8 +123,8 @@
 #ifndef FC_SPEC
 #define FC_SPEC 0
 #endif
-#if FC_SPEC && (FC_VARIANT_BIG || FC_VARIANT_WIDE || (defined(FC_GRAM_TRI) && FC_GRAM_TRI))
-#error "FC_SPEC is a variant of the 256-thread default build"
+#if FC_SPEC && (FC_VARIANT_BIG || (defined(FC_GRAM_TRI) && FC_GRAM_TRI))
+#error "FC_SPEC is a variant of the default geometry with full Gram tables (256 or 1024 threads)"
 #endif
 /* FC_SCAN_SL: the matching-pursuit scan recomputes a candidate from its table rows in every pass
  * (mp_sl.inc) instead of carrying it through the call in registers (mp_reg.inc) */
@@ -3384,8 +3390,10 @@ extern "C" void FC_LAUNCH(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, u
 {
     hipLaunchKernelGGL(FC_KERNEL, dim3(n * G), dim3(B), 0, stream, d_frames, d_vframes, G);
 }
-extern "C" unsigned fc_spec_slot_bytes(void) { return SPEC_STRIDE; }
+extern "C" unsigned FC_SPEC_SLOT_BYTES(void) { return SPEC_STRIDE; }
+#if !FC_VARIANT_WIDE
 extern "C" unsigned fc_spec_ctl_bytes(void) { return (unsigned) ((sizeof(FcSpecCtl) + 255) / 256 * 256); }
+#endif
 #else
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                           const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream)

@@ -7,6 +7,8 @@ import synth, fiasco_amd
 w, h, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 modes = sys.argv[4:] or ["0", "default"]
 lib = fiasco_amd.library(); lib.set_verbosity(0); opt = lib.cli_options()
+if max(w, h) > 2048:
+    lib.set_limits(30000, 26)
 if os.environ.get("PROBE_COLOR"):
     if max(w, h) > 1280: lib.set_limits(30000, 26)
     frames = [synth.ppm_bytes(synth.synth_color_k(w, h, 1234 if i == 0 else 1000 + i)) for i in range(n)]

@@ -1411,7 +1411,7 @@ static bool launch_wave(Staged *S)
         }
         const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * max_slot, 256);
         const size_t off_tabs = align_up(off_blocks + max_blocks * 4, 256);
-        const size_t span = align_up(off_tabs + (T ? (size_t) FC_SPEC_R * max_tab : 0), 256);
+        const size_t span = align_up(off_tabs + (size_t) FC_SPEC_R * max_tab, 256);
         std::vector<size_t> priv(nall);
         size_t need = span * nall;
         for (size_t i = 0; i < nall; i++) {
@@ -1477,7 +1477,10 @@ static bool launch_wave(Staged *S)
                 FcSpecCtl h;
                 memset(&h, 0, sizeof h);
                 h.slot_bytes = (unsigned) max_slot;
-                h.n_blocks = T ? (unsigned) (lists[i].size() / 2) : 0u;
+                /* a colour frame: the chroma bands' tables too, from every workgroup but the chain (even
+                 * without table workers for the luminance band) */
+                h.n_blocks = (unsigned) (lists[i].size() / 2);
+                h.n_tabs = hf[first_all + i].color ? 3u * h.n_blocks : (T ? h.n_blocks : 0u);
                 h.tab_stride = (unsigned) max_tab;
                 /* 120 us: about what the chain needs to build the tables itself (tests: FIASCO_AMD_SPEC_TABWAIT=0
                  * makes it take the worker's tables only when they are there already) */

@@ -212,6 +212,11 @@ typedef struct FcSpecCtl {
     unsigned s_pub;             /* states whose table rows are complete and visible (chain, at its checkpoints) */
     unsigned tab_free;          /* blocks below this index need their table buffer no more (chain) */
     unsigned blk_cur;           /* the block the chain is at (chain) */
+    /* chroma bands of a colour frame: their tables are a function of the pixels and of the finished
+     * luminance dictionary alone -- once the chain has set chroma_ready, EVERY other workgroup of the
+     * frame builds them (block list once more per band; blocks handed out by tab_next) */
+    unsigned chroma_ready, tab_next, ystates;
+    unsigned n_tabs;            /* blocks with tables from workers: n_blocks, or 3 n_blocks for a colour frame (host) */
     unsigned n_blocks;          /* entries of the block list (host) */
     unsigned tab_stride;        /* bytes per table buffer: ipis [NS][P], then d5 [NA][P] (host) */
     unsigned tab_wait;          /* ticks (100 MHz) the chain waits for a worker's tables before it builds them itself (host) */

@@ -374,6 +374,7 @@ struct Sh {
         char     *slots;           /* FC_SPEC_W checkpoints of sizeof(Sh) bytes */
         int       role, on;        /* 0 chain, 1 .. T table workers, then verifiers; on: the frame speculates at all */
         int       T;
+        int       chroma_tabs;     /* chain, chroma bands of a colour frame: the other workgroups build the blocks' tables */
         char     *tabs;            /* FC_SPEC_R table buffers */
         unsigned  rb_s[32];        /* chain: state count it returned to at the end of epoch e, [e % 32] */
         unsigned  blkof[FC_SPEC_W];    /* chain: block index of the checkpoint in a slot */
@@ -2173,7 +2174,8 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 if (wall_clock64() - t0 > 100000000ull) { sh.failed = FC_ERR_INTERNAL; break; }     /* 1 s */
                 __builtin_amdgcn_s_sleep(32);
             }
-            sh.sl.on = 0;                        /* the rest of the frame is the chain's alone */
+            sh.sl.on = 0;                        /* no more guesses: the chroma bands are searched by the chain ... */
+            sh.sl.chroma_tabs = c->n_tabs > c->n_blocks;      /* ... with tables from all the other workgroups (OP_CHROMA) */
         }
 #endif
         if (sp < 0) {
@@ -2257,6 +2259,10 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 const unsigned oldest = sh.sl.commit != sh.sl.head ? sh.sl.blkof[sh.sl.commit % FC_SPEC_W] : (unsigned) sh.blk;
                 __hip_atomic_store(&c->tab_free, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&c->blk_cur, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (sh.sl.chroma_tabs && sh.sl.role == 0 && rg.level == sh.par.lc_max && sh.band) {
+                FcSpecCtl *c = sh.sl.ctl;
+                __hip_atomic_store(&c->tab_free, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->blk_cur, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #endif
             fr.price = sh.par.price;
@@ -2277,7 +2283,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 rg.address = rg.image = 0;
                 sh.op = OP_INIT_RANGE; sh.a0 = rg.x; sh.a1 = rg.y;
 #if FC_SPEC
-                sh.a2 = sh.band ? -1 : sh.blk++;      /* index of the block in the host's list */
+                sh.a2 = (!sh.band || sh.sl.chroma_tabs) ? sh.blk++ : -1;      /* index of the block in the host's list (+ blocks per band) */
 #endif
                 return 0;
             }
@@ -2754,7 +2760,7 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
         FcSpecCtl *c = sl.ctl;
         const unsigned b = (unsigned) blk % FC_SPEC_R;
         int from = -1;
-        if ((unsigned) blk < c->n_blocks) {
+        if ((unsigned) blk < c->n_tabs) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
                 if (__hip_atomic_load(&c->tab_seq[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) blk + 1) {
@@ -2762,7 +2768,7 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
                     const unsigned te = __hip_atomic_load(&c->tab_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (sl.epoch - te > 32u) S = 0;
                     else for (unsigned e = te; e != sl.epoch; e++) if (sl.rb_s[e % 32u] < S) S = sl.rb_s[e % 32u];
-                    from = (int) S < sh.states ? (int) S : sh.states;
+                    from = (int) S < table_states(sh) ? (int) S : table_states(sh);
                     break;
                 }
                 if (wall_clock64() - t0 > c->tab_wait) break;
@@ -2781,6 +2787,78 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     /* the worker's entries, not this CU's stale lines */
+}
+#endif
+
+#if FC_SPEC
+/* Table worker (all lanes; returns when the chain is done).  Luminance band: workgroup `role` of the T
+ * workers builds the tables of every T-th block of the host's list, ahead of the chain, for the states
+ * the chain has published, into the buffer blk % FC_SPEC_R.  Chroma bands of a colour frame (block
+ * indices from n_blocks on; dynamic: a verifier that has turned worker): blocks handed out one by one. */
+__device__ __noinline__ void spec_worker(DevFrame &__restrict__ F, Sh &__restrict__ sh, unsigned role, unsigned T, bool dynamic)
+{
+    __shared__ int tw_x, tw_y, tw_go;
+    __shared__ unsigned tw_e0;
+    const int tid = threadIdx.x;
+    FcSpecCtl *const c = F.spec;
+    unsigned j = role - 1;                      /* lane 0's */
+    const unsigned short *blocks = (const unsigned short *) ((const char *) c + c->off_blocks);
+    if (tid == 0) { sh.band = 0; sh.gap_lo = sh.gap_hi = 0; sh.deadmask = 0; sh.sl.role = (int) role; sh.ystates = 0; }
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            int go = 1;
+            const unsigned nb = c->n_blocks;
+            bool have = false;                  /* dynamic: j is a block taken from tab_next */
+            for (;;) {
+                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                if (!dynamic) {
+                    const unsigned cur = __hip_atomic_load(&c->blk_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (j + 1 < cur) j += T;           /* the chain is past these (it may still wait for block cur - 1) */
+                    if (j >= nb) dynamic = true;
+                }
+                if (dynamic) {
+                    if (!__hip_atomic_load(&c->chroma_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) || c->n_tabs <= nb) {
+                        __builtin_amdgcn_s_sleep(64);
+                        continue;
+                    }
+                    if (!have) { j = nb + atomicAdd(&c->tab_next, 1u); have = true; }
+                    if (j >= c->n_tabs) { __builtin_amdgcn_s_sleep(64); continue; }       /* nothing left: wait for the end */
+                }
+                if (j < __hip_atomic_load(&c->tab_free, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + FC_SPEC_R
+                    && __hip_atomic_load(&c->s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            tw_go = go;
+            if (go) {
+                const unsigned b = j % FC_SPEC_R;
+                __hip_atomic_store(&c->tab_seq[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                /* the epoch first: a return of the chain lowers s_pub before it raises the epoch */
+                tw_e0 = __hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned S = __hip_atomic_load(&c->s_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned band = j / nb;
+                if (band) S = c->ystates;                 /* the finished luminance dictionary */
+                sh.band = (int) band; sh.states = (int) S; sh.ystates = (int) S;
+                sh.par.ipis = (float *) ((char *) c + c->off_tabs + (size_t) b * c->tab_stride);
+                sh.par.d5 = sh.par.ipis + (size_t) F.NS * F.P;
+                tw_x = blocks[2 * (j % nb)]; tw_y = blocks[2 * (j % nb) + 1];
+            }
+        }
+        __syncthreads();
+        if (!tw_go) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        op_init_range(F, sh, tw_x, tw_y, 0);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned b = j % FC_SPEC_R;
+            __hip_atomic_store(&c->tab_s[b], (unsigned) sh.states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->tab_epoch[b], tw_e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->tab_seq[b], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (dynamic) j = c->n_tabs + 1;     /* take the next one */
+            else j += T;
+        }
+    }
 }
 #endif
 
@@ -2913,6 +2991,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sl.ctl = F.spec; sl.slots = F.spec ? SPEC_SLOTS(F.spec) : nullptr;
         sl.role = (int) role; sl.on = F.spec != nullptr && G > 1;
         sl.T = F.spec_T; sl.tabs = F.spec ? (char *) F.spec + F.spec->off_tabs : nullptr;
+        sl.chroma_tabs = 0;
         sl.n_tab_used = sl.n_tab_missed = 0;
         for (int k = 0; k < 32; k++) sl.rb_s[k] = 0;
         sh.blk = 0; sh.tab_shared = 0; sh.tab_from = 0;
@@ -3093,57 +3172,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&F.spec->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (role >= 1 && role <= T) {
-        /* table worker: the tables of every T-th block of the host's list, ahead of the chain, for the
-         * states the chain has published, into the buffer blk % FC_SPEC_R */
-        FcSpecCtl *const c = F.spec;
-        __shared__ int tw_x, tw_y;
-        unsigned j = role - 1;
-        const unsigned short *blocks = (const unsigned short *) ((const char *) c + c->off_blocks);
-        if (tid == 0) { sh.band = 0; sh.gap_lo = sh.gap_hi = 0; sh.deadmask = 0; sh.sl.role = (int) role; }
-        for (;;) {
-            __syncthreads();
-            if (tid == 0) {
-                int go = 1;
-                for (;;) {
-                    if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
-                    const unsigned cur = __hip_atomic_load(&c->blk_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (j + 1 < cur) j += T;               /* the chain is past these (it may still wait for block cur - 1) */
-                    if (j < c->n_blocks
-                        && j < __hip_atomic_load(&c->tab_free, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + FC_SPEC_R
-                        && __hip_atomic_load(&c->s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                task_go = go;
-                if (go) {
-                    const unsigned b = j % FC_SPEC_R;
-                    __hip_atomic_store(&c->tab_seq[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    /* the epoch first: a return of the chain lowers s_pub before it raises the epoch */
-                    const unsigned e0 = __hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned S = __hip_atomic_load(&c->s_pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    task_seq = e0;
-                    sh.states = (int) S;
-                    sh.par.ipis = (float *) ((char *) c + c->off_tabs + (size_t) b * c->tab_stride);
-                    sh.par.d5 = sh.par.ipis + (size_t) F.NS * F.P;
-                    tw_x = blocks[2 * j]; tw_y = blocks[2 * j + 1];
-                }
-            }
-            __syncthreads();
-            if (!task_go) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            op_init_range(F, sh, tw_x, tw_y, 0);
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned b = j % FC_SPEC_R;
-                __hip_atomic_store(&c->tab_s[b], (unsigned) sh.states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->tab_epoch[b], task_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->tab_seq[b], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                j += T;
-            }
-        }                                           /* (j is lane 0's) */
-        return;
-    }
+    if (role >= 1 && role <= T) { spec_worker(F, sh, role, T, false); return; }
     for (;;) {          /* chain: once.  Verifier: once per block it verifies, until the chain is done. */
     if (role) {
         FcSpecCtl *const c = F.spec;
@@ -3154,12 +3183,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             for (;;) {
                 if (__hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == t + 1) break;
                 if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                /* colour frame, luminance band done: nothing left to verify, the chroma bands' tables to build */
+                if (__hip_atomic_load(&c->chroma_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 2; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
             task_seq = t; task_go = go;
         }
         __syncthreads();
-        if (!task_go) break;                                      /* uniform */
+        if (task_go != 1) break;                                  /* uniform */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        /* nothing stale in this CU's L1 */
         {   /* the chain's LDS state at the entry of the block */
             const uint4 *src = (const uint4 *) (SPEC_SLOTS(c) + (size_t) (task_seq % FC_SPEC_W) * SPEC_STRIDE);
@@ -3261,7 +3292,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #endif
 #if FC_SPEC
         case OP_INIT_RANGE:
-            if (sh.sl.on && sh.sl.role == 0 && sh.sl.T > 0 && sh.a2 >= 0) spec_tables(F, sh, sh.a2);
+            if (((sh.sl.on && sh.sl.T > 0) || sh.sl.chroma_tabs) && sh.sl.role == 0 && sh.a2 >= 0) spec_tables(F, sh, sh.a2);
             else if (tid == 0) { sh.tab_from = 0; if (sh.sl.role == 0) { sh.par.ipis = F.ipis; sh.par.d5 = F.d5; sh.tab_shared = 0; } }
             __syncthreads();
             op_init_range(F, sh, sh.a0, sh.a1, sh.tab_from);
@@ -3272,7 +3303,20 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         case OP_APPROX:     op_approx(F, sh); break;
         case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
         case OP_APPEND:     op_append(F, sh, sh.a0); break;
-        case OP_CHROMA:     op_chroma_pool(F, sh); break;
+        case OP_CHROMA:
+            op_chroma_pool(F, sh);
+#if FC_SPEC
+            if (sh.sl.chroma_tabs) {                 /* uniform: the luminance dictionary is final and visible */
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) {
+                    FcSpecCtl *c = sh.sl.ctl;
+                    c->ystates = (unsigned) sh.ystates;
+                    __hip_atomic_store(&c->chroma_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#endif
+            break;
 #if FC_VARIANT_BIG
         case OP_PRED_SETUP:  op_pred_setup(F, sh, sh.a0, sh.a1); break;
         case OP_PRED_FINISH: op_pred_finish(F, sh, sh.a0); break;
@@ -3317,7 +3361,10 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         if (sh.sl.busy) { __threadfence(); atomicSub(&F.spec->busy, 1u); }      /* its rows are written */
     }
     }
-    if (role) return;
+    if (role) {
+        if (task_go == 2) spec_worker(F, sh, role, T, true);
+        return;
+    }
     if (tid == 0 && sh.sl.ctl && G > 1) {
         FcSpecCtl *const c = sh.sl.ctl;
         /* verifiers that are still at a block the chain went back behind drop it; the others leave */

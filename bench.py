@@ -118,10 +118,19 @@ def small_launches(lib, opt, uniq, w, h):
     one (wide) workgroup per frame (FIASCO_AMD_SPEC=0); the streams must be the same bytes.  Outside
     the timed region of the headline figure."""
     import fiasco_amd
+    import synth
     res = {}
-    for name, frames in (("single_frame", uniq[:1]), ("batch_of_16", uniq[:16])):
-        if len(frames) < (1 if name == "single_frame" else 16):
+    # BASELINE config 3 (colour 1080p: needs the declared limits extension, SURVEY 8c) and one 4K frame
+    colour = [synth.ppm_bytes(synth.synth_color_k(w, h))]
+    gray4k = [synth.pgm_bytes(synth.synth(3840, 2160, 1234))]
+    for name, frames in (("single_frame", uniq[:1]), ("batch_of_16", uniq[:16]), ("single_colour_frame", colour),
+                         ("single_4k_frame", gray4k)):
+        if len(frames) < (16 if name == "batch_of_16" else 1):
             continue
+        big = name in ("single_colour_frame", "single_4k_frame")
+        if big:
+            lib.set_limits(30000, 26)
+        o = lib.cli_options()
         ent, ref = {}, None
         for key, env in (("several_workgroups_per_frame", None), ("one_workgroup_per_frame", "0")):
             if env is None:
@@ -129,7 +138,7 @@ def small_launches(lib, opt, uniq, w, h):
             else:
                 os.environ["FIASCO_AMD_SPEC"] = env
             try:
-                b = fiasco_amd.Batch(lib, frames, 20.0, opt)
+                b = fiasco_amd.Batch(lib, frames, 20.0, o)
                 b.encode()
                 best = None
                 for _ in range(3):
@@ -148,6 +157,9 @@ def small_launches(lib, opt, uniq, w, h):
                         "workgroups_per_frame_launches": int(st.spec_frames), "identical_streams": out == ref,
                         "blocks_confirmed": int(st.spec_confirmed), "blocks_sent_back": int(st.spec_wrong),
                         "blocks_searched_by_the_chain": int(st.spec_inline)}
+        o.delete()
+        if big:
+            lib.set_limits(6000, 22)
         res[name] = ent
     return res
 

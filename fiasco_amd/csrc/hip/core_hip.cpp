@@ -1335,7 +1335,9 @@ static bool launch_wave(Staged *S)
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
                     /* groups 5, 6: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
                     const bool spec = fs.spec && S->specG >= 2 && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
-                    const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only);
+                    /* (FIASCO_AMD_SPEC_WIDE=0 / 1: experiments with the width of the workgroups) */
+                    const char *sw = getenv("FIASCO_AMD_SPEC_WIDE");
+                    const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only || (sw && atoi(sw) == 1));
                     if ((spec ? (spec_wide ? 6 : 5) : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;

@@ -2118,7 +2118,9 @@ __device__ int spec_poll(Sh &sh, bool drain)
         const unsigned slot = sl.commit % FC_SPEC_W;
         const bool mine = (sl.spec_mask >> slot) & 1u;
         if (!mine) { sl.commit++; t0 = 0; continue; }     /* searched here anyway: whatever the verifier says */
-        const unsigned v = __hip_atomic_load(&c->verdict[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        /* relaxed: the word guards no data (an acquire would drop the chain's L1 at every look; what a
+         * return reads is the chain's own checkpoint, behind a fence of its own) */
+        const unsigned v = __hip_atomic_load(&c->verdict[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 2) != sl.commit + 1) {                   /* not there yet */
             if (!drain && sl.head - sl.commit < FC_SPEC_W) return 0;
             const unsigned long long now = wall_clock64();
@@ -2252,7 +2254,6 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             /* entry of a block of the largest block level: verdicts that have arrived, then the
              * checkpoint of this block (OP_SPEC_CKPT; the node is entered again afterwards) */
             if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band) {
-                if (spec_poll(sh, false)) return 0;
                 /* table workers: where the chain is, and which buffers it needs no more (those of the
                  * blocks below the oldest one that still waits for its verdict) */
                 FcSpecCtl *c = sh.sl.ctl;
@@ -2763,7 +2764,7 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
         if ((unsigned) blk < c->n_tabs) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
-                if (__hip_atomic_load(&c->tab_seq[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) blk + 1) {
+                if (__hip_atomic_load(&c->tab_seq[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) blk + 1) {   /* (fence below) */
                     unsigned S = __hip_atomic_load(&c->tab_s[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned te = __hip_atomic_load(&c->tab_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (sl.epoch - te > 32u) S = 0;

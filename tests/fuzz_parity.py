@@ -6,7 +6,9 @@ sizes, RPF mantissas/ranges, chroma options -- encoded by both libraries through
 fiasco_amd_encode_batch; any byte difference is reported with the seed that reproduces it.
 
 usage: fuzz_parity.py [rounds] [frames_per_round] [seed0]
-environment: FUZZ_PRED=1 also intra prediction with random level windows; FUZZ_BIG=1 sizes up to 1000 x 800; FUZZ_REPL=n every frame n times in one launch (the
+environment: FUZZ_SPEC=1 only option sets of the default geometry (block levels 6..10, <= 3 vectors, no
+retries: the kernel builds that give a frame several workgroups), every round with a random split of
+the workgroups (block-level speculation); FUZZ_PRED=1 also intra prediction with random level windows; FUZZ_BIG=1 sizes up to 1000 x 800; FUZZ_REPL=n every frame n times in one launch (the
 replicas must agree: a full device exposes timing-dependent faults that single frames hide)
 """
 import os
@@ -57,6 +59,9 @@ def random_options(rng, lib=None):
     if os.environ.get("FUZZ_PRED") == "1" and rng.integers(0, 4):     # intra prediction (ND)
         plo = int(rng.integers(6, 11))
         pred = (1, plo, int(rng.integers(plo, 13)))
+    if os.environ.get("FUZZ_SPEC") == "1":
+        lo, hi, el, lvl, pred = 6, 10, int(rng.integers(1, 4)), 0, (0, 6, 10)
+        mant = int(rng.integers(2, 5))
     spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred)
     return spec
 
@@ -92,6 +97,15 @@ def main():
             os.environ["FIASCO_AMD_NO_WIDE"] = "1"
         else:
             os.environ.pop("FIASCO_AMD_NO_WIDE", None)
+        if os.environ.get("FUZZ_SPEC") == "1":          # several workgroups per frame, random split
+            os.environ.pop("FIASCO_AMD_NO_WIDE", None)
+            G = int(rng.integers(2, 9))
+            os.environ["FIASCO_AMD_SPEC"] = str(G)
+            os.environ["FIASCO_AMD_SPEC_T"] = str(int(rng.integers(0, max(1, G - 1))))
+            if rng.integers(0, 3) == 0:
+                os.environ["FIASCO_AMD_SPEC_TABWAIT"] = "0"
+            else:
+                os.environ.pop("FIASCO_AMD_SPEC_TABWAIT", None)
         print("round seed %d spec %s q %s" % (seed0 + r, spec, q), flush=True)
         repl = int(os.environ.get("FUZZ_REPL", "1"))    # FUZZ_REPL=n: every frame n times in the launch
         got_all = gpu.encode_batch(frames * repl, q, og)

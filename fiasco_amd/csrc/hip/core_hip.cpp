@@ -978,10 +978,12 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         /* (colour: the luminance band; not with y_column flags carried in from an earlier frame of the
          * stream -- the states a block search appends and removes again clear them id by id, and a
          * verifier's ids are not the chain's) */
-        if (specG && !fs.big && !jobs[i].ycol_carry) {
+        /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
+        const bool build1 = !specG && getenv("FIASCO_AMD_SPEC_BUILD1") != nullptr;
+        if ((specG || build1) && !fs.big && !jobs[i].ycol_carry) {
             /* the 256-thread build up to 3072 states, the 1024-thread one (4K; frames beyond the narrow
              * build's LDS pools) up to 12288 */
-            const size_t withids = align_up(guess + (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS, 64);
+            const size_t withids = align_up(guess + (build1 ? 0 : (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS), 64);
             if (withids <= 12 * 1024 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
         }
         /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
@@ -1334,7 +1336,7 @@ static bool launch_wave(Staged *S)
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
                     /* groups 5, 6: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
-                    const bool spec = fs.spec && S->specG >= 2 && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
+                    const bool spec = fs.spec && (S->specG >= 2 || getenv("FIASCO_AMD_SPEC_BUILD1")) && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
                     /* (FIASCO_AMD_SPEC_WIDE=0 / 1: experiments with the width of the workgroups) */
                     const char *sw = getenv("FIASCO_AMD_SPEC_WIDE");
                     const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only || (sw && atoi(sw) == 1));
@@ -1389,7 +1391,12 @@ static bool launch_wave(Staged *S)
     bool fail = false;
     S->spec_frames.clear();
     S->spec_first[0] = S->spec_first[1] = 0; S->spec_n[0] = S->spec_n[1] = 0;
-    if (group_n[5] + group_n[6]) {
+    if (group_n[5] + group_n[6] && S->specG < 2) {       /* FIASCO_AMD_SPEC_BUILD1: the build alone */
+        const size_t nall = group_n[5] + group_n[6], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[5];
+        S->spec_first[1] = first_all + group_n[5]; S->spec_n[1] = group_n[6];
+        for (size_t i = 0; i < nall; i++) hf[first_all + i].spec = nullptr;
+    } else if (group_n[5] + group_n[6]) {
         /* the speculating frames (groups 5 and 6: 256 / 1024 threads per workgroup; they are the last of
          * the batch): control block + checkpoint slots + block list + table ring per frame, then per
          * verifier workgroup its private <sub-block, state> tables, scan scratch and pool list; verifier

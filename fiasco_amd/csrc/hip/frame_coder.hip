@@ -123,6 +123,9 @@
 #ifndef FC_SPEC
 #define FC_SPEC 0
 #endif
+#ifndef SPEC_THR
+#define SPEC_THR 1.2f          /* FC_SPEC: see SpecLocal.mlc */
+#endif
 #if FC_SPEC && (FC_VARIANT_BIG || (defined(FC_GRAM_TRI) && FC_GRAM_TRI))
 #error "FC_SPEC is a variant of the default geometry with full Gram tables (256 or 1024 threads)"
 #endif
@@ -156,7 +159,8 @@
 enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA,
        OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH, OP_SPEC_CKPT, OP_SPEC_ROLLBACK };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
-       PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO };
+       PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO,
+       PH_SPEC_END };
 enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
 #if FC_VARIANT_BIG
 #define FC_DEPTH FC_MAXDEPTH_BIG
@@ -363,7 +367,7 @@ struct Sh {
      * states its own search appends, which get ids from gap_hi on (a private index range of every
      * table of the shared slab); the ids in between belong to the chain, which is ahead and still
      * writes them: nothing may look at them.  Chain: gap_lo == gap_hi == 0. */
-    int      gap_lo, gap_hi;
+    int      gap_lo, gap_hi, gap_shift;        /* gap_shift = gap_hi - gap_lo: what the gap adds to a state count */
     unsigned deadmask;             /* scan slots (B candidates each) that lie inside the gap */
     int      cap;                  /* state ids of this workgroup end here (FC_ERR_CAPACITY) */
     int      blk;                  /* chain: blocks of the largest block level entered so far (index into the host's list) */
@@ -373,6 +377,7 @@ struct Sh {
         FcSpecCtl *ctl;
         char     *slots;           /* FC_SPEC_W checkpoints of sizeof(Sh) bytes */
         int       role, on;        /* 0 chain, 1 .. T table workers, then verifiers; on: the frame speculates at all */
+        int       mode;            /* the same for the partition search: 0, 1 (chain, on), 2 + floor (verifier) */
         int       T;
         int       chroma_tabs;     /* chain, chroma bands of a colour frame: the other workgroups build the blocks' tables */
         char     *tabs;            /* FC_SPEC_R table buffers */
@@ -392,6 +397,7 @@ struct Sh {
          * than SPEC_THR x the running mean over the blocks that kept theirs are searched here. */
         float     mlc, lin[FC_SPEC_W];
         unsigned  nlc;
+        float     learn;           /* costs of a combination that won in a search of the chain's own, not yet in mlc */
         unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
     } sl;
 #endif
@@ -2102,18 +2108,18 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 }
 
 #if FC_SPEC
-#ifndef SPEC_THR
-#define SPEC_THR 1.2f
-#endif
 #define SPEC_TIMEOUT_TICKS 20000000ull      /* 0.2 s of the 100 MHz wall clock: then the chain does the block itself */
 /* Chain, lane 0: consume the verdicts that have arrived, in block order.  `drain`: wait for all of
- * them (end of the frame); otherwise wait only while every checkpoint slot is taken.  Returns 1 when
- * the chain has to go back to a checkpoint (sh.op / sh.a0 say which). */
-__device__ int spec_poll(Sh &sh, bool drain)
+ * them (end of the frame); otherwise wait only while every checkpoint slot is taken.  Returns 0, or 1 +
+ * the checkpoint slot the chain has to go back to.  (Called from the workgroup's operation loop, not from
+ * the partition search: a call inside serial_advance() costs every one of its invocations the saving
+ * and restoring of registers through scratch memory -- 7 % of a frame, measured.) */
+__device__ __noinline__ int spec_poll(Sh &sh, bool drain)
 {
     Sh::SpecLocal &sl = sh.sl;
     FcSpecCtl *c = sl.ctl;
     unsigned long long t0 = 0;
+    if (sl.learn != 0.0f) { sl.mlc = sl.nlc ? 0.9f * sl.mlc + 0.1f * sl.learn : sl.learn; sl.nlc++; sl.learn = 0.0f; }
     while (sl.commit != sl.head) {
         const unsigned slot = sl.commit % FC_SPEC_W;
         const bool mine = (sl.spec_mask >> slot) & 1u;
@@ -2137,10 +2143,28 @@ __device__ int spec_poll(Sh &sh, bool drain)
             }
             sl.n_wrong++;
         }
-        sh.op = OP_SPEC_ROLLBACK; sh.a0 = (int) slot;
-        return 1;
+        return 1 + (int) slot;
     }
     return 0;
+}
+#endif
+
+#if FC_SPEC
+/* Chain, lane 0, end of the luminance band of a colour frame: the chroma bands number their states on
+ * into the verifiers' id ranges.  No block search may start from here on (epoch), none may still be
+ * running (a verifier looks at the epoch every few operations). */
+__device__ __noinline__ void spec_luminance_done(Sh &sh)
+{
+    FcSpecCtl *c = sh.sl.ctl;
+    sh.sl.epoch++;
+    __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (wall_clock64() - t0 > 100000000ull) { sh.failed = FC_ERR_INTERNAL; break; }     /* 1 s */
+        __builtin_amdgcn_s_sleep(32);
+    }
+    sh.sl.on = 0; sh.sl.mode = 0;        /* no more guesses: the chroma bands are searched by the chain ... */
+    sh.sl.chroma_tabs = c->n_tabs > c->n_blocks;      /* ... with tables from all the other workgroups (OP_CHROMA) */
 }
 #endif
 
@@ -2160,28 +2184,21 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
     const int ML = sh.par.ML;
     {
 #if FC_SPEC
-        if (sh.sl.role > 0 && sp < sh.sl.floor) {        /* not reached: a verifier ends in PH_DECIDE of its block */
-            sh.sl.verdict = 2; sh.op = OP_DONE; return 0;
-        }
-        if (sp < 0 && sh.sl.on && spec_poll(sh, true)) { sh.sp = sp; return 0; }     /* a wrong guess: back */
-        if (sp < 0 && sh.sl.on && sh.par.color && !sh.band && !sh.after_chroma) {
-            /* end of the luminance band of a colour frame: the chroma bands number their states on into
-             * the verifiers' id ranges.  No block search may start from here on (epoch), none may still
-             * be running (a verifier looks at the epoch every few operations). */
-            FcSpecCtl *c = sh.sl.ctl;
-            sh.sl.epoch++;
-            __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                if (wall_clock64() - t0 > 100000000ull) { sh.failed = FC_ERR_INTERNAL; break; }     /* 1 s */
-                __builtin_amdgcn_s_sleep(32);
-            }
-            sh.sl.on = 0;                        /* no more guesses: the chroma bands are searched by the chain ... */
-            sh.sl.chroma_tabs = c->n_tabs > c->n_blocks;      /* ... with tables from all the other workgroups (OP_CHROMA) */
-        }
+        /* what this workgroup is: 0 one workgroup per frame (or a chain that guesses no more), 1 a chain
+         * that guesses, 2 + floor a verifier.  Read afresh in every transition: a plain read is hoisted
+         * out of the loop of transitions (FC_SERIAL_LOOP) and then lives in a register of its own for
+         * the whole of serial_advance() -- one more callee-saved register to save and restore through
+         * scratch memory per call, three calls per range */
+        const int spec_mode = *(volatile int *) &sh.sl.mode;
 #endif
         if (sp < 0) {
             sh.sp = sp;
+#if FC_SPEC
+            if (spec_mode == 1) {                /* end of the band: every verdict, then no more guesses */
+                sh.op = OP_SPEC_CKPT; sh.a0 = 2;
+                return 0;
+            }
+#endif
             const int more = band_advance(F, sh);        /* may push the root of the next band */
             sp = sh.sp; phase = sp >= 0 ? sh.st[sp].phase : 0;
             if (!more) { sh.op = OP_DONE; return 0; }
@@ -2253,18 +2270,6 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #if FC_SPEC
             /* entry of a block of the largest block level: verdicts that have arrived, then the
              * checkpoint of this block (OP_SPEC_CKPT; the node is entered again afterwards) */
-            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band) {
-                /* table workers: where the chain is, and which buffers it needs no more (those of the
-                 * blocks below the oldest one that still waits for its verdict) */
-                FcSpecCtl *c = sh.sl.ctl;
-                const unsigned oldest = sh.sl.commit != sh.sl.head ? sh.sl.blkof[sh.sl.commit % FC_SPEC_W] : (unsigned) sh.blk;
-                __hip_atomic_store(&c->tab_free, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->blk_cur, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (sh.sl.chroma_tabs && sh.sl.role == 0 && rg.level == sh.par.lc_max && sh.band) {
-                FcSpecCtl *c = sh.sl.ctl;
-                __hip_atomic_store(&c->tab_free, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->blk_cur, (unsigned) sh.blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
 #endif
             fr.price = sh.par.price;
             if (sh.band) fr.price *= sh.par.chroma_decrease;
@@ -2295,9 +2300,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #if FC_SPEC
             /* a block of the largest block level, its tables done: verdicts that have arrived, then
              * the checkpoint of this block (OP_SPEC_CKPT; the phase is entered again afterwards) */
-            if (sh.sl.on && sh.sl.role == 0 && rg.level == sh.par.lc_max && !sh.band && !fr.ckpt) {
-                if (spec_poll(sh, false)) return 0;
-                if (!sh.sl.nospec && rg.level > sh.lc_min) { fr.ckpt = 1; sh.op = OP_SPEC_CKPT; return 0; }
+            if (spec_mode == 1 && rg.level == sh.par.lc_max && !sh.band && !fr.ckpt && sp > 0) {
+                fr.ckpt = 1; sh.op = OP_SPEC_CKPT; sh.a0 = 1;        /* the operation sets ckpt = 2 if it takes a checkpoint */
+                return 0;
             }
 #endif
             /* A range that cannot be subdivided needs no model snapshots at all: a rejected
@@ -2363,19 +2368,10 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #endif
             }
 #if FC_SPEC
-            if (sh.sl.role == 0 && fr.ckpt && rg.level == sh.par.lc_max) {
-                const unsigned slot = (sh.sl.head - 1) % FC_SPEC_W;      /* this block's checkpoint */
-                if (sh.sl.nospec) {
-                    sh.sl.nospec = 0;            /* back from a wrong guess: this block is searched here */
-                    sh.sl.n_inline++;
-                } else if (fr.lincomb < (sh.sl.nlc >= 8 ? SPEC_THR * sh.sl.mlc : MAXCOSTS) && !sh.failed) {
-                    /* the guess: the combination wins.  Its verifier searches the block. */
-                    sh.sl.spec_mask |= 1u << slot;
-                    sh.sl.lin[slot] = fr.lincomb;
-                    fr.subdiv = MAXCOSTS;
-                    phase = PH_DECIDE;
-                    break;
-                } else sh.sl.n_inline++;
+            if (fr.ckpt == 3) {                  /* the guess (spec_guess, end of OP_APPROX): the combination wins */
+                fr.subdiv = MAXCOSTS;
+                phase = PH_DECIDE;
+                break;
             }
 #endif
             if (rg.level > sh.lc_min) {
@@ -2506,7 +2502,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
         case PH_DECIDE: {
             Range &rg = fr.rg;
 #if FC_SPEC
-            if (sh.sl.role > 0 && sp == sh.sl.floor) {
+            if (spec_mode >= 2 && sp == spec_mode - 2) {
                 /* the verifier's block: all the chain needs to know is whether the combination wins
                  * (the branch `lincomb < subdiv` below) */
                 sh.sl.verdict = (!sh.failed && !fr.leaf && fr.lincomb < MAXCOSTS && fr.lincomb < fr.subdiv) ? 1 : 2;
@@ -2534,10 +2530,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 goto pop;
             } else if (fr.lincomb < fr.subdiv) {
 #if FC_SPEC
-                if (sh.sl.role == 0 && fr.ckpt && rg.level == sh.par.lc_max
-                    && !((sh.sl.spec_mask >> ((sh.sl.head - 1) % FC_SPEC_W)) & 1u)) {    /* searched here, kept its combination */
-                    sh.sl.mlc = sh.sl.nlc ? 0.9f * sh.sl.mlc + 0.1f * fr.lincomb : fr.lincomb; sh.sl.nlc++;
-                }
+                if (fr.ckpt == 2 && spec_mode == 1) sh.sl.learn = fr.lincomb;    /* searched here, kept its combination */
 #endif
                 sh.pool = fr.pool_lc;
                 snap_load(F, sh, sp, 1);
@@ -2560,7 +2553,8 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 if (F.pred_on && sh.pool.n >= sh.pool.max_domains) aux = 1;
 #endif
 #if FC_SPEC
-                if (sh.states >= (sh.band ? sh.par.PA : sh.cap)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
+                /* (volatile: see spec_mode) */
+                if (sh.states >= (sh.band ? sh.par.PA : *(volatile int *) &sh.cap)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
 #else
                 if (sh.states >= (sh.band ? sh.par.PA : sh.par.P)) { sh.failed = FC_ERR_CAPACITY; fr.ret = MAXCOSTS; goto pop; }
 #endif
@@ -2570,10 +2564,17 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 break;
             }
         }
+#if FC_SPEC
+        case PH_SPEC_END: {                  /* a verifier's block has left the stack without a verdict (not reached:
+                                              * it ends in PH_DECIDE of the block): the chain does the block itself */
+            sh.sl.verdict = 2; sh.op = OP_DONE;
+            return 0;
+        }
+#endif
         case PH_AFTER_APPEND: {
             sh.states++;
 #if FC_SPEC
-            if (sh.states - (sh.gap_hi - sh.gap_lo) >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
+            if (sh.states - *(volatile int *) &sh.gap_shift >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
 #else
             if (sh.states >= sh.par.limit_states) sh.failed = FC_ERR_STATES;
 #endif
@@ -2761,6 +2762,13 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
         FcSpecCtl *c = sl.ctl;
         const unsigned b = (unsigned) blk % FC_SPEC_R;
         int from = -1;
+        {   /* for the table workers: where the chain is, and which buffers it needs no more (those of the
+             * blocks below the oldest one that still waits for its verdict; in the chroma bands none does) */
+            unsigned oldest = (unsigned) blk;
+            if (!sh.band && sl.commit != sl.head) oldest = sl.blkof[sl.commit % FC_SPEC_W];
+            __hip_atomic_store(&c->tab_free, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->blk_cur, (unsigned) blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if ((unsigned) blk < c->n_tabs) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
@@ -2927,8 +2935,8 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     __shared__ Sh sh;
 #if FC_SPEC
     __shared__ Sh::SpecLocal sl_keep;
-    __shared__ unsigned task_seq;
-    __shared__ int task_go;
+    __shared__ unsigned task_seq, spec_slot;
+    __shared__ int task_go, spec_act;
     const unsigned role = blockIdx.x % G;
     DevFrame &F = role ? vframes[(blockIdx.x / G) * (G - 1) + role - 1] : frames[blockIdx.x / G];
     unsigned long long *const ring = nullptr;
@@ -2987,17 +2995,18 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #if FC_SPEC
     if (tid == 0) {
         Sh::SpecLocal &sl = sh.sl;
-        sh.gap_lo = sh.gap_hi = 0; sh.deadmask = 0;
+        sh.gap_lo = sh.gap_hi = 0; sh.gap_shift = 0; sh.deadmask = 0;
         sh.cap = F.spec ? F.spec_cap : F.P;
         sl.ctl = F.spec; sl.slots = F.spec ? SPEC_SLOTS(F.spec) : nullptr;
         sl.role = (int) role; sl.on = F.spec != nullptr && G > 1;
+        sl.mode = role == 0 && sl.on ? 1 : 0;
         sl.T = F.spec_T; sl.tabs = F.spec ? (char *) F.spec + F.spec->off_tabs : nullptr;
         sl.chroma_tabs = 0;
         sl.n_tab_used = sl.n_tab_missed = 0;
         for (int k = 0; k < 32; k++) sl.rb_s[k] = 0;
         sh.blk = 0; sh.tab_shared = 0; sh.tab_from = 0;
         sl.floor = 0; sl.head = sl.commit = 0; sl.spec_mask = 0; sl.nospec = 0; sl.epoch = 0;
-        sl.verdict = 0; sl.abort = 0; sl.ops = 0; sl.mlc = 0.0f; sl.nlc = 0;
+        sl.verdict = 0; sl.abort = 0; sl.ops = 0; sl.mlc = 0.0f; sl.nlc = 0; sl.learn = 0.0f;
         sl.n_tasks = sl.n_confirmed = sl.n_wrong = sl.n_timeout = sl.n_inline = sl.t_wait = 0;
         sl_keep = sl;
     }
@@ -3210,7 +3219,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             const int S0 = sh.states, TB = F.spec_tb;
             if (valid && (S0 > TB || sh.sp < 0 || sh.sp >= FC_DEPTH)) valid = false;
             sh.sl.floor = sh.sp; sh.sl.verdict = 2; sh.sl.abort = valid ? 0 : 1; sh.sl.ops = 0; sh.sl.busy = 0;
-            sh.gap_lo = S0; sh.gap_hi = TB; sh.states = TB; sh.cap = TB + FC_SPEC_TEMPS;
+            sh.sl.mode = 2 + sh.sp;
+            if (sh.sp > 0) sh.st[sh.sp - 1].phase = PH_SPEC_END;     /* what the block's parent does should the block ever return */
+            sh.gap_lo = S0; sh.gap_hi = TB; sh.gap_shift = TB - S0; sh.states = TB; sh.cap = TB + FC_SPEC_TEMPS;
             unsigned dm = 0;
             for (int k = 0; k < 32; k++) if (k * B >= S0 && (k + 1) * B <= TB) dm |= 1u << k;
             sh.deadmask = dm;
@@ -3243,51 +3254,64 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         switch (op) {
 #if FC_SPEC
         case OP_SPEC_CKPT: {
-            /* the complete LDS state of the chain at the entry of a block: what a verifier starts
-             * from, and what the chain returns to if its guess about the block is wrong */
+            /* a0 = 1, a block of the largest block level with its tables done: the verdicts that have
+             * arrived, then the checkpoint of this block -- the complete LDS state of the chain: what a
+             * verifier starts from, and what the chain returns to if its guess about the block is wrong.
+             * a0 = 2, end of the band: every verdict.  Either way a verdict may send the chain back. */
             FcSpecCtl *const c = sh.sl.ctl;
-            const unsigned seq = sh.sl.head, slot = seq % FC_SPEC_W;
-            if (tid == 0) __hip_atomic_store(&c->slot_seq[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            __syncthreads();
-            uint4 *dst = (uint4 *) (sh.sl.slots + (size_t) slot * SPEC_STRIDE);
-            for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) dst[i] = ((const uint4 *) &sh)[i];
-            __threadfence();                 /* + every table row written so far */
-            __syncthreads();
             if (tid == 0) {
-                /* every table row of the states so far is complete and visible: table workers may use them */
-                __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
-                sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
-            }
-            break;
-        }
-        case OP_SPEC_ROLLBACK: {
-            FcSpecCtl *const c = sh.sl.ctl;
-            const unsigned slot = (unsigned) sh.a0;
-            if (tid == 0) sl_keep = sh.sl;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            const uint4 *src = (const uint4 *) (sl_keep.slots + (size_t) slot * SPEC_STRIDE);
-            for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
-            __syncthreads();
-            if (tid == 0) {
-                sh.sl = sl_keep;
-                sh.sl.nospec = 1;                     /* this block is searched here */
-                sh.sl.commit = sh.sl.head;            /* every verification in flight is void ... */
-                /* the rows of the states from here on will be written again: tables computed from them
-                 * in this epoch or before count up to here only (spec_tables), and nothing beyond is
-                 * offered to the table workers until the next checkpoint */
-                sh.sl.rb_s[sh.sl.epoch % 32u] = (unsigned) sh.states;
-                __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                sh.sl.epoch++;                        /* ... and its verifier should drop it */
-                __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int act = 0;
+                const int back = spec_poll(sh, sh.a0 == 2);
+                if (back) { act = 2; spec_slot = (unsigned) (back - 1); }
+                else if (sh.a0 == 1) {
+                    SFrame &fr = sh.st[sh.sp];
+                    if (!sh.sl.nospec && fr.rg.level > sh.lc_min) { fr.ckpt = 2; act = 1; }
+                } else if (sh.par.color && !sh.band && !sh.after_chroma) spec_luminance_done(sh);
+                else { sh.sl.on = 0; sh.sl.mode = 0; }       /* a gray frame: it is over */
+                spec_act = act;
             }
             __syncthreads();
-            /* the checkpoint was taken with the block's tables done.  In a buffer of the ring they still
-             * are; the chain's own tables have been those of later blocks since: once more */
-            if (!sh.tab_shared) op_init_range(F, sh, sh.st[sh.sp].rg.x, sh.st[sh.sp].rg.y, 0);
+            if (spec_act == 1) {
+                const unsigned seq = sh.sl.head, slot = seq % FC_SPEC_W;
+                if (tid == 0) __hip_atomic_store(&c->slot_seq[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                __syncthreads();
+                uint4 *dst = (uint4 *) (sh.sl.slots + (size_t) slot * SPEC_STRIDE);
+                for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) dst[i] = ((const uint4 *) &sh)[i];
+                __threadfence();                 /* + every table row written so far */
+                __syncthreads();
+                if (tid == 0) {
+                    /* every table row of the states so far is complete and visible: table workers may use them */
+                    __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
+                    sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
+                }
+            } else if (spec_act == 2) {
+                const unsigned slot = spec_slot;
+                if (tid == 0) sl_keep = sh.sl;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+                const uint4 *src = (const uint4 *) (sl_keep.slots + (size_t) slot * SPEC_STRIDE);
+                for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
+                __syncthreads();
+                if (tid == 0) {
+                    sh.sl = sl_keep;
+                    sh.sl.nospec = 1;                     /* this block is searched here */
+                    sh.sl.commit = sh.sl.head;            /* every verification in flight is void ... */
+                    /* the rows of the states from here on will be written again: tables computed from them
+                     * in this epoch or before count up to here only (spec_tables), and nothing beyond is
+                     * offered to the table workers until the next checkpoint */
+                    sh.sl.rb_s[sh.sl.epoch % 32u] = (unsigned) sh.states;
+                    __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    sh.sl.epoch++;                        /* ... and its verifier should drop it */
+                    __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                /* the checkpoint was taken with the block's tables done.  In a buffer of the ring they still
+                 * are; the chain's own tables have been those of later blocks since: once more */
+                if (!sh.tab_shared) op_init_range(F, sh, sh.st[sh.sp].rg.x, sh.st[sh.sp].rg.y, 0);
+            }
             break;
         }
 #endif
@@ -3395,7 +3419,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     if (tid == 0) for (int k = 0; k < 8; k++) F.dbg[k] = sh.pm[k];
 #endif
 #if FC_SPEC && !defined(FC_PM) && !defined(FC_SERIAL_PROFILE)
-    if (tid == 0) { F.dbg[0] = tk[OP_SPEC_CKPT]; F.dbg[1] = tk[OP_SPEC_ROLLBACK]; }   /* ticks of the chain in the two ops */
+    if (tid == 0) { F.dbg[0] = tk[OP_SPEC_CKPT]; F.dbg[1] = 0; }   /* ticks of the chain in checkpoints, verdicts and returns */
 #endif
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */

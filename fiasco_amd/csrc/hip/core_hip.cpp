@@ -623,7 +623,7 @@ static void spec_block_list(const DevFrame &F, std::vector<uint16_t> &out)
     }
 }
 
-static int spec_groups(size_t frames, int cus)
+static int spec_groups(size_t frames, int cus, bool big_frames)
 {
     const char *e = getenv("FIASCO_AMD_SPEC");
     if (e && atoi(e) <= 1) return 0;
@@ -637,13 +637,18 @@ static int spec_groups(size_t frames, int cus)
         if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
         return G >= 2 ? (int) G : 0;
     }
-    /* by default only while every workgroup has a CU to itself (measured, 1080p: 1 frame 1.8 x, 16
-     * frames 1.6 x the rate of one wide workgroup per frame; with two workgroups per CU the verifiers
-     * take from the chains what they give, with four the launch is slower) and with at least three
-     * verifiers per chain (one or two keep it waiting) */
+    /* by default only while every workgroup has a CU to itself (measured, 1080p: 1 frame 3 x, 16
+     * frames 2.7 x, 64 frames (4 workgroups each) 1.7 x, 85 frames (3 each) 1.4 x the rate of one wide
+     * workgroup per frame; with two workgroups per CU the verifiers take from the chains what they
+     * give, with four the launch is slower) and with at least two verifiers per chain (one keeps it
+     * waiting: slower than no speculation at all) */
     size_t G = (size_t) cus / frames;
     if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
-    return G >= 4 ? (int) G : 0;
+    /* 4K frames (the 1024-thread build; tables of megabytes per block): more than half the CUs busy
+     * with them and they slow each other down -- 32 frames: 7.2 frames/s with 8 workgroups each, 7.9
+     * with 6, 9.1 with 4 */
+    if (big_frames && G > 4 && 2 * frames * G > (size_t) cus) G = (size_t) cus / (2 * frames) >= 4 ? (size_t) cus / (2 * frames) : 4;
+    return G >= 3 ? (int) G : 0;
 }
 
 static inline const fa_image *slot_image(const Staged *S, const FrameSlot &fs)
@@ -947,7 +952,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         int dev = 0, ncu = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        specG = spec_groups(n, ncu);
+        specG = spec_groups(n, ncu, n > 0 && jobs[0].image && (jobs[0].image->width > 2048 || jobs[0].image->height > 2048));
         S->specG = specG;
     }
     if (hipStreamCreate(&S->stream) != hipSuccess || hipEventCreate(&S->ev0) != hipSuccess

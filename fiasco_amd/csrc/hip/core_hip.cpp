@@ -980,12 +980,9 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.P = (int) align_up(guess, 64);
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
-        /* (colour: the luminance band; not with y_column flags carried in from an earlier frame of the
-         * stream -- the states a block search appends and removes again clear them id by id, and a
-         * verifier's ids are not the chain's) */
-        /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
+                /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
         const bool build1 = !specG && getenv("FIASCO_AMD_SPEC_BUILD1") != nullptr;
-        if ((specG || build1) && !fs.big && !jobs[i].ycol_carry) {
+        if ((specG || build1) && !fs.big) {
             /* the 256-thread build up to 3072 states, the 1024-thread one (4K; frames beyond the narrow
              * build's LDS pools) up to 12288 */
             const size_t withids = align_up(guess + (build1 ? 0 : (size_t) (specG - 1 - spec_workers(specG)) * FC_SPEC_TEMPS), 64);

@@ -204,7 +204,7 @@ typedef struct FcSpecCtl {
     unsigned busy;              /* verifiers inside a block search (the chain waits for 0 before the chroma bands re-use their state ids) */
     unsigned slot_bytes;        /* size of a checkpoint slot */
     unsigned slot_seq[FC_SPEC_W];   /* seq + 1 once the checkpoint of block `seq` is complete, 0 while written */
-    unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 2 | code: 1 the combination wins, 2 anything else */
+    unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 8 | state ids the search used << 2 | code: 1 the combination wins, 2 anything else */
     /* statistics (chain) */
     unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
     unsigned long long n_tab_used, n_tab_missed;      /* blocks whose tables came from a worker / were not there in time */

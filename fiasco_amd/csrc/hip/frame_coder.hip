@@ -383,6 +383,7 @@ struct Sh {
         char     *tabs;            /* FC_SPEC_R table buffers */
         unsigned  rb_s[32];        /* chain: state count it returned to at the end of epoch e, [e % 32] */
         unsigned  blkof[FC_SPEC_W];    /* chain: block index of the checkpoint in a slot */
+        unsigned  sk[FC_SPEC_W];       /* chain: states at that checkpoint */
         unsigned long long n_tab_used, n_tab_missed;
         int       floor;           /* verifier: stack depth of the block it verifies */
         unsigned  head, commit;    /* chain: checkpoints published / verdicts consumed */
@@ -2127,7 +2128,7 @@ __device__ __noinline__ int spec_poll(Sh &sh, bool drain)
         /* relaxed: the word guards no data (an acquire would drop the chain's L1 at every look; what a
          * return reads is the chain's own checkpoint, behind a fence of its own) */
         const unsigned v = __hip_atomic_load(&c->verdict[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 2) != sl.commit + 1) {                   /* not there yet */
+        if ((v >> 8) != sl.commit + 1) {                   /* not there yet */
             if (!drain && sl.head - sl.commit < FC_SPEC_W) return 0;
             const unsigned long long now = wall_clock64();
             if (!t0) t0 = now;
@@ -2137,6 +2138,16 @@ __device__ __noinline__ int spec_poll(Sh &sh, bool drain)
         } else {
             if (t0) { sl.t_wait += wall_clock64() - t0; t0 = 0; }
             if ((v & 3u) == 1u) {
+                /* colour: every state the block's search appended (and removed again) had its y_column
+                 * flags written -- zeros, in the luminance band (codec/subdivide.c:560-567) -- under the id it
+                 * had in the chain's numbering; the flags outlive the states (codec/wfalib.c:283-309) and
+                 * the stream shows them.  The verifier used ids of its own and wrote nothing: here, for as
+                 * many ids as its search ever used. */
+                if (sh.par.color) {
+                    GLOBAL_AS uint8_t *yc = (GLOBAL_AS uint8_t *) sh.par.at_ycol;
+                    const unsigned used = (v >> 2) & 63u, s0 = sl.sk[slot];
+                    for (unsigned j = 0; j < used; j++) { yc[s0 + j] = 0; yc[(unsigned) sh.par.PA + s0 + j] = 0; }
+                }
                 sl.mlc = sl.nlc ? 0.9f * sl.mlc + 0.1f * sl.lin[slot] : sl.lin[slot]; sl.nlc++;
                 sl.commit++; sl.n_confirmed++;
                 continue;
@@ -3227,6 +3238,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             sh.deadmask = dm;
             sh.par.at_pool = F.pool_states;                       /* private pool list */
             sh.par.trace_on = 0;
+            sh.par.color = 0;                                     /* no y_column flags from here: spec_poll */
+            /* which of this workgroup's ids the search uses is read off their level entries afterwards */
+            for (int k = 0; k < FC_SPEC_TEMPS; k++) F.level_of_state[TB + k] = 0;
             sh.op = valid ? OP_NOP : OP_DONE;
             if (valid) {
                 atomicAdd(&c->busy, 1u);
@@ -3286,6 +3300,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                     __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
                     sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
+                    sh.sl.sk[slot] = (unsigned) sh.states;
                 }
             } else if (spec_act == 2) {
                 const unsigned slot = spec_slot;
@@ -3380,9 +3395,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     if (!role) break;
     __syncthreads();
     if (tid == 0) {
-        if (!sh.sl.abort)
-            __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W], ((task_seq + 1) << 2) | (unsigned) sh.sl.verdict,
+        if (!sh.sl.abort) {
+            /* (seq + 1) << 8 | ids the search used << 2 | verdict */
+            unsigned used = 0;
+            while (used < FC_SPEC_TEMPS && F.level_of_state[sh.gap_hi + (int) used] != 0) used++;
+            __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W],
+                               ((task_seq + 1) << 8) | (used << 2) | (unsigned) sh.sl.verdict,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (sh.sl.busy) { __threadfence(); atomicSub(&F.spec->busy, 1u); }      /* its rows are written */
     }
     }

@@ -3199,10 +3199,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         FcSpecCtl *const c = F.spec;
         __syncthreads();
         if (tid == 0) {
-            const unsigned t = atomicAdd(&c->next, 1u);
+            unsigned t = atomicAdd(&c->next, 1u);
             int go = 1;
             for (;;) {
-                if (__hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == t + 1) break;
+                const unsigned q = __hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (q == t + 1) break;
+                /* the slot already holds a LATER block: the chain went back behind block t, dropped it and has
+                 * come round to the slot again before anybody looked at it.  Waiting for it would be for ever. */
+                if (q > t + 1) { t = atomicAdd(&c->next, 1u); continue; }
                 if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
                 /* colour frame, luminance band done: nothing left to verify, the chroma bands' tables to build */
                 if (__hip_atomic_load(&c->chroma_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 2; break; }
@@ -3326,6 +3330,10 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                 /* the checkpoint was taken with the block's tables done.  In a buffer of the ring they still
                  * are; the chain's own tables have been those of later blocks since: once more */
                 if (!sh.tab_shared) op_init_range(F, sh, sh.st[sh.sp].rg.x, sh.st[sh.sp].rg.y, 0);
+                /* Verdicts that do not come (every wait for one is bounded, but 0.2 s each): the verifiers are
+                 * not resident, or too few for a chain this fast.  Three of them and this frame goes on
+                 * without guesses -- one workgroup, as if it had no others. */
+                if (tid == 0 && sh.sl.n_timeout >= 3) { sh.sl.on = 0; sh.sl.mode = 0; }
             }
             break;
         }

@@ -404,7 +404,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None,
                          "traffic": pmc_traffic(F, a.width, a.height),
-                         "kernel": "fiasco_frame_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "kernel": ("fiasco_frame_kernel_spec" + ("_wide" if max(a.width, a.height) > 2048 else "")
+                                    if st is not None and st.spec_frames else "fiasco_frame_kernel"),
+                         "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
         }
         if dry:

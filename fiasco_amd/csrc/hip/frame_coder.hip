@@ -157,7 +157,7 @@
 #define MIN_NORM 2e-3f
 
 enum { OP_DONE = 0, OP_INIT_RANGE, OP_APPROX, OP_IPIS_INCR, OP_APPEND, OP_NOP, OP_CHROMA,
-       OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH, OP_SPEC_CKPT, OP_SPEC_ROLLBACK };
+       OP_PRED_SETUP, OP_PRED_FINISH, OP_NORMS, OP_MC_SEARCH, OP_SPEC_CKPT };
 enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_RET, PH_DECIDE,
        PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO,
        PH_SPEC_END };

@@ -387,7 +387,7 @@ extern "C" void fiasco_amd_release_memory(void)
 /* ------------------------------------------------------------------ layout */
 
 struct Layout {
-    size_t gram, diag, ipis, cmax, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
+    size_t gram, gcol, diag, ipis, cmax, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
@@ -406,6 +406,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 #define CARVE(field, bytes) do { L.field = o; o = align_up(o + (bytes), 256); } while (0)
     /* Gram tables: full symmetric, or (tri) the lower triangle with packed rows + a row of slack */
     CARVE(gram, tri ? (size_t) NL * ((size_t) P * (P + 1) / 2 + P) * 4 : (size_t) NL * P * P * 4);
+    CARVE(gcol, tri ? (size_t) NL * FC_TRI_HOT * P * 4 : 0);      /* columns of the first states as rows (frame_coder.h) */
     CARVE(diag, (size_t) NL * P * 4);
     CARVE(ipis, (size_t) NS * P * 4);
     CARVE(cmax, (size_t) NS * (P / 64) * 4);        /* per heap slot and 64-state block (frame_coder.hip op_ipis) */
@@ -707,6 +708,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.gram = (float *) (base + L.gram); F.diag = (float *) (base + L.diag);
     F.ipis = (float *) (base + L.ipis); F.d5 = (float *) (base + L.d5);
     F.cmax = (float *) (base + L.cmax);
+    F.gcol = (float *) (base + L.gcol);
     F.d4 = (float *) (base + L.d4); F.imgT4 = (float *) (base + L.imgT4);
     F.img = (float *) (base + L.img); F.imgT = (float *) (base + L.imgT);
     F.norms = (float *) (base + L.norms);

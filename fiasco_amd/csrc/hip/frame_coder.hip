@@ -349,6 +349,7 @@ struct Sh {
         int lc_max, width, height, limit_states, PA, P, ML; float price, chroma_decrease;
         /* the same for the matching pursuit: table bases and quantiser parameters */
         float *gram, *diag, *ipis; int16_t *pos; unsigned gram_ls;
+        float *gcol;               /* triangular build: DevFrame.gcol */
         float *d5, *d4;            /* big build: the active level-5 / level-4 dot tables */
         const unsigned *l2_keys; const double *l2_vals; unsigned l2_mask;
         int max_elements, rpf_mant, dc_mant, sy, dcs, gl0, images_level, lc_min_opt, trace_on;
@@ -527,6 +528,8 @@ __device__ void gram_store(const DevFrame &F, int q, int s, int t, float v)
     G[GROW(s, F.P) + (unsigned) t] = v;
 #if !FC_GRAM_TRI
     G[(size_t) t * F.P + s] = v;
+#else
+    if (t < FC_TRI_HOT && t < s) F.gcol[((size_t) q * FC_TRI_HOT + t) * F.P + s] = v;
 #endif
     if (s == t) F.diag[(size_t) q * F.P + s] = v;
 }
@@ -1136,6 +1139,9 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                 for (int k = 0; k < 32; k++) v0 += vs[k] * vt[k];
                 stg(gram, (unsigned) (q1 - 1) * LS + rs + (unsigned) t, v0);
                 if (s == t) stg(diag, (unsigned) ((q1 - 1) * Pu + s), v0);
+#if FC_GRAM_TRI
+                if (t < FC_TRI_HOT && t < s) F.gcol[((size_t) (q1 - 1) * FC_TRI_HOT + t) * Pu + s] = v0;
+#endif
             }
             for (int q = q1; q < F.NL; q++) {
                 /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
@@ -1176,6 +1182,9 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                 }
                 stg(gram, (unsigned) q * LS + rs + (unsigned) t, ip);
                 if (s == t) stg(diag, (unsigned) (q * Pu + s), ip);
+#if FC_GRAM_TRI
+                if (t < FC_TRI_HOT && t < s) F.gcol[((size_t) q * FC_TRI_HOT + t) * Pu + s] = ip;
+#endif
             }
         }
     }
@@ -3154,6 +3163,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.par.limit_states = F.limit_states; sh.par.PA = F.PA; sh.par.P = F.P; sh.par.ML = F.ML;
         sh.par.price = F.price; sh.par.chroma_decrease = F.chroma_decrease;
         sh.par.gram = F.gram; sh.par.gram_ls = F.gram_ls; sh.par.diag = F.diag; sh.par.ipis = F.ipis; sh.par.pos = F.pos;
+        sh.par.gcol = F.gcol;
         sh.par.d5 = F.d5; sh.par.d4 = F.d4;
         sh.par.at_tree = F.tree; sh.par.at_into = F.into; sh.par.at_pool = F.pool_states; sh.par.at_weight = F.weight;
         sh.par.at_final = F.final_d; sh.par.at_los = F.level_of_state; sh.par.at_dtype = F.domain_type;

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth, fiasco_amd
 w, h, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 modes = sys.argv[4:] or ["0", "default"]
-lib = fiasco_amd.library(); lib.set_verbosity(0); opt = lib.cli_options()
+lib = fiasco_amd.Library(os.environ["FIASCO_AMD_LIB"]) if os.environ.get("FIASCO_AMD_LIB") else fiasco_amd.library()
+lib.set_verbosity(0); opt = lib.cli_options()
 if max(w, h) > 2048:
     lib.set_limits(30000, 26)
 if os.environ.get("PROBE_COLOR"):

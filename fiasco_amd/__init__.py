@@ -66,7 +66,7 @@ class Stats(ctypes.Structure):
                 ("spec_confirmed", ctypes.c_ulonglong), ("spec_wrong", ctypes.c_ulonglong),
                 ("spec_timeout", ctypes.c_ulonglong), ("spec_inline", ctypes.c_ulonglong),
                 ("spec_wait", ctypes.c_ulonglong), ("spec_tab_used", ctypes.c_ulonglong),
-                ("spec_tab_missed", ctypes.c_ulonglong)]
+                ("spec_tab_missed", ctypes.c_ulonglong), ("spec_adopted", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):

@@ -1422,7 +1422,7 @@ static bool launch_wave(Staged *S)
             const size_t slot = i < group_n[5] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
             if (slot > max_slot) max_slot = slot;
         }
-        const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) FC_SPEC_W * max_slot, 256);
+        const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) 2 * FC_SPEC_W * max_slot, 256);      /* checkpoint + result slots */
         const size_t off_tabs = align_up(off_blocks + max_blocks * 4, 256);
         const size_t span = align_up(off_tabs + (size_t) FC_SPEC_R * max_tab, 256);
         std::vector<size_t> priv(nall);
@@ -1584,6 +1584,7 @@ static void complete_wave(Staged *S)
                 g_stats.spec_wrong += ctl[i].n_wrong; g_stats.spec_timeout += ctl[i].n_timeout;
                 g_stats.spec_inline += ctl[i].n_inline; g_stats.spec_wait += ctl[i].t_wait;
                 g_stats.spec_tab_used += ctl[i].n_tab_used; g_stats.spec_tab_missed += ctl[i].n_tab_missed;
+                g_stats.spec_adopted += ctl[i].n_adopted;
             }
         else (void) hipGetLastError();
     }
@@ -1693,7 +1694,8 @@ static void complete_wave(Staged *S)
             else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
             else if (st == FC_ERR_QUEUE) msg = "device coder: frame queue gave no slab";
             else if (st == FC_ERR_INTERNAL) msg = "device coder: frame exceeds a built-in capacity (recursion depth, snapshot stack or 16384 states)";
-            snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
+            if (st > FC_ERR_QUEUE) snprintf(job->errmsg, sizeof job->errmsg, "%s (status %d)", msg, st);
+            else snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);
         }
     }
     (void) hipStreamSynchronize(S->stream);

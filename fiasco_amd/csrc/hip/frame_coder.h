@@ -187,7 +187,9 @@ typedef struct DevFrame {
  *
  *  Per frame, in HBM: this control block, then FC_SPEC_W checkpoint slots of sizeof(Sh) bytes (the
  *  complete LDS state of the chain at the entry of a block: input of the verifier, and what the
- *  chain returns to after a wrong guess).
+ *  chain returns to after a wrong guess), then FC_SPEC_W result slots of the same size (a verifier
+ *  that finds the subdivision of its block to win leaves its own LDS state there: the chain takes it
+ *  over instead of searching the block again).
  *
  *  Table workers.  A third of what is left to the chain is init_range: the <sub-block, state> tables
  *  of the next block for every state of the dictionary (codec/ip.c:72-154, codec/subdivide.c:612-644).
@@ -207,6 +209,8 @@ typedef struct FcSpecCtl {
     unsigned next;              /* verifiers: next sequence number to take */
     unsigned epoch;             /* bumped by the chain whenever it goes back: verifications in flight are void */
     unsigned done;              /* the chain has finished the frame */
+    unsigned committed;         /* blocks below this sequence number have had their verdict looked at, or were not waited for (chain) */
+    unsigned adopting;          /* the chain moves the rows of a verifier's states to its own ids: nobody searches, the verifier keeps off its ids */
     unsigned busy;              /* verifiers inside a block search (the chain waits for 0 before the chroma bands re-use their state ids) */
     unsigned slot_bytes;        /* size of a checkpoint slot */
     unsigned slot_seq[FC_SPEC_W];   /* seq + 1 once the checkpoint of block `seq` is complete, 0 while written */
@@ -214,6 +218,7 @@ typedef struct FcSpecCtl {
     /* statistics (chain) */
     unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
     unsigned long long n_tab_used, n_tab_missed;      /* blocks whose tables came from a worker / were not there in time */
+    unsigned long long n_adopted;                     /* wrong guesses after which the chain took over the verifier's state */
     /* table workers */
     unsigned s_pub;             /* states whose table rows are complete and visible (chain, at its checkpoints) */
     unsigned tab_free;          /* blocks below this index need their table buffer no more (chain) */

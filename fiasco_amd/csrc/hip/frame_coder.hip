@@ -385,7 +385,7 @@ struct Sh {
         unsigned  rb_s[32];        /* chain: state count it returned to at the end of epoch e, [e % 32] */
         unsigned  blkof[FC_SPEC_W];    /* chain: block index of the checkpoint in a slot */
         unsigned  sk[FC_SPEC_W];       /* chain: states at that checkpoint */
-        unsigned long long n_tab_used, n_tab_missed;
+        unsigned long long n_tab_used, n_tab_missed, n_adopted;
         int       floor;           /* verifier: stack depth of the block it verifies */
         unsigned  head, commit;    /* chain: checkpoints published / verdicts consumed */
         unsigned  spec_mask;       /* chain: per slot, the block's subtree was left to its verifier */
@@ -2137,8 +2137,11 @@ __device__ __noinline__ int spec_poll(Sh &sh, bool drain)
         /* relaxed: the word guards no data (an acquire would drop the chain's L1 at every look; what a
          * return reads is the chain's own checkpoint, behind a fence of its own) */
         const unsigned v = __hip_atomic_load(&c->verdict[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 8) != sl.commit + 1) {                   /* not there yet */
-            if (!drain && sl.head - sl.commit < FC_SPEC_W) return 0;
+        if ((v >> 11) != sl.commit + 1) {                  /* not there yet */
+            if (!drain && sl.head - sl.commit < FC_SPEC_W) {
+                __hip_atomic_store(&c->committed, sl.commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0;
+            }
             const unsigned long long now = wall_clock64();
             if (!t0) t0 = now;
             if (now - t0 < SPEC_TIMEOUT_TICKS) { __builtin_amdgcn_s_sleep(16); continue; }
@@ -2162,9 +2165,16 @@ __device__ __noinline__ int spec_poll(Sh &sh, bool drain)
                 continue;
             }
             sl.n_wrong++;
+            /* take over the verifier's state -- unless the states its search appended do not fit below the
+             * verifiers' ids any more: then the chain searches the block itself and runs out of ids the
+             * ordinary way (FC_ERR_CAPACITY, the host stages the frame again with more) */
+            if ((v & 3u) == 3u && sl.sk[slot] + ((v >> 2) & 63u) <= (unsigned) sh.cap)
+                return (1 + (int) slot) | 0x100 | (int) (((v >> 2) & 63u) << 16) | (int) (((v >> 8) & 7u) << 24);
         }
         return 1 + (int) slot;
     }
+    /* (verifiers that wait with a result the chain did not ask for -- a block it searched itself -- go on) */
+    __hip_atomic_store(&c->committed, sl.commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0;
 }
 #endif
@@ -2526,6 +2536,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 /* the verifier's block: all the chain needs to know is whether the combination wins
                  * (the branch `lincomb < subdiv` below) */
                 sh.sl.verdict = (!sh.failed && !fr.leaf && fr.lincomb < MAXCOSTS && fr.lincomb < fr.subdiv) ? 1 : 2;
+                /* 3: the subdivision wins (the last branch below).  The chain need not search the block
+                 * again: it takes over this workgroup's state as it stands here (OP_SPEC_CKPT) */
+                if (!sh.failed && !fr.leaf && fr.subdiv < MAXCOSTS && !(fr.lincomb < fr.subdiv)) sh.sl.verdict = 3;
                 sh.op = OP_DONE;
                 return 0;
             }
@@ -2955,8 +2968,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     __shared__ Sh sh;
 #if FC_SPEC
     __shared__ Sh::SpecLocal sl_keep;
-    __shared__ unsigned task_seq, spec_slot;
-    __shared__ int task_go, spec_act;
+    __shared__ unsigned task_seq, spec_slot, spec_used, spec_vid;
+    __shared__ int task_go, spec_act, spec_bad;
+    if (threadIdx.x == 0) spec_bad = 0;
     const unsigned role = blockIdx.x % G;
     DevFrame &F = role ? vframes[(blockIdx.x / G) * (G - 1) + role - 1] : frames[blockIdx.x / G];
     unsigned long long *const ring = nullptr;
@@ -3022,7 +3036,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sl.mode = role == 0 && sl.on ? 1 : 0;
         sl.T = F.spec_T; sl.tabs = F.spec ? (char *) F.spec + F.spec->off_tabs : nullptr;
         sl.chroma_tabs = 0;
-        sl.n_tab_used = sl.n_tab_missed = 0;
+        sl.n_tab_used = sl.n_tab_missed = sl.n_adopted = 0;
         for (int k = 0; k < 32; k++) sl.rb_s[k] = 0;
         sh.blk = 0; sh.tab_shared = 0; sh.tab_from = 0;
         sl.floor = 0; sl.head = sl.commit = 0; sl.spec_mask = 0; sl.nospec = 0; sl.epoch = 0;
@@ -3290,7 +3304,25 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             if (tid == 0) {
                 int act = 0;
                 const int back = spec_poll(sh, sh.a0 == 2);
-                if (back) { act = 2; spec_slot = (unsigned) (back - 1); }
+                if (back) {
+                    act = (back & 0x100) ? 3 : 2; spec_slot = (unsigned) ((back & 0xff) - 1);
+                    spec_used = (unsigned) (back >> 16) & 63u; spec_vid = (unsigned) (back >> 24) & 7u;
+                    if (act == 3) {
+                        /* the state to take over is what this block's verifier left: anything else is a bug */
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        const Sh *im = (const Sh *) (sh.sl.slots + (size_t) (FC_SPEC_W + spec_vid) * SPEC_STRIDE);
+                        const int TB = im->gap_hi, S0 = im->gap_lo, m = im->states - TB;
+                        int bad = 0;
+                        if (S0 != (int) sh.sl.sk[spec_slot]) bad |= 1;
+                        if (TB < F.spec_cap || TB + FC_SPEC_TEMPS > F.P || ((TB - F.spec_cap) % FC_SPEC_TEMPS)) bad |= 2;
+                        if (m < 0 || m > FC_SPEC_TEMPS || m > (int) spec_used) bad |= 4;
+                        if (im->sp < 1 || im->sp >= FC_DEPTH) bad |= 8;
+                        if (im->sl.epoch != sh.sl.epoch) bad |= 16;
+                        if (S0 + m > F.spec_cap) bad |= 32;
+                        if (im->sl.verdict != 3 || im->failed) bad |= 64;
+                        if (bad) { spec_bad |= bad; act = 2; }
+                    }
+                }
                 else if (sh.a0 == 1) {
                     SFrame &fr = sh.st[sh.sp];
                     if (!sh.sl.nospec && fr.rg.level > sh.lc_min) { fr.ckpt = 2; act = 1; }
@@ -3316,6 +3348,92 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                     sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
                     sh.sl.sk[slot] = (unsigned) sh.states;
                 }
+            } else if (spec_act == 3) {
+                /* A wrong guess whose verifier found the subdivision to win: instead of going back to the
+                 * checkpoint and searching the block again, the chain takes over the verifier's state at the
+                 * decision of the block -- models, stack, the block's children -- and the states its search
+                 * has appended: their rows move from the verifier's ids (from TB on) to the chain's (from the
+                 * block's state count on), references to them with them.  Same values as a search of the
+                 * chain's own: same code on the same inputs. */
+                if (tid == 0) sl_keep = sh.sl;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+                const uint4 *src = (const uint4 *) (sl_keep.slots + (size_t) (FC_SPEC_W + spec_vid) * SPEC_STRIDE);
+                for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
+                __syncthreads();
+                const int TB = sh.gap_hi, S0 = sh.gap_lo, m = sh.states - TB, shift = TB - S0;
+                __syncthreads();
+                if (tid == 0) {
+                    sh.sl = sl_keep;
+                    sh.sl.nospec = 0;
+                    sh.sl.commit = sh.sl.head;
+                    sh.sl.rb_s[sh.sl.epoch % 32u] = (unsigned) S0;
+                    __hip_atomic_store(&c->s_pub, (unsigned) S0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    /* Rows from S0 on are about to change under every verification in flight (all void: they
+                     * started from later checkpoints).  Half-moved rows must not be searched -- a state's
+                     * position in the pool and the counters of a later checkpoint need not agree: first the
+                     * epoch, then wait until every search has seen it.  The verifier whose rows move waits
+                     * for `adopting` to clear before it uses its ids again. */
+                    __hip_atomic_store(&c->adopting, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    sh.sl.epoch++;
+                    __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);
+                    sh.sl.n_adopted++;
+                    sh.gap_lo = sh.gap_hi = sh.gap_shift = 0; sh.deadmask = 0;
+                    sh.cap = F.spec_cap;
+                    sh.states = S0 + m;
+                    sh.par.at_pool = F.pool_states; sh.par.color = F.color; sh.par.trace_on = 0;
+                    if (!sh.tab_shared) { sh.par.ipis = F.ipis; sh.par.d5 = F.d5; }
+                    sh.st[sh.sp - 1].phase = PH_CHILD_RET;               /* (the verifier's terminal phase) */
+                    SFrame &fr = sh.st[sh.sp];
+                    fr.states = S0;
+                    for (int l = 0; l < 2; l++) {
+                        Range &ch = fr.child[l];
+                        if (ch.tree >= TB) ch.tree -= shift;
+                        for (int e = 0; e < RANGE_E; e++) if (ch.into[e] >= TB) ch.into[e] = (short) (ch.into[e] - shift);
+                    }
+                    if (F.color) {                                       /* see spec_poll: flags of the ids the search used */
+                        GLOBAL_AS uint8_t *yc = (GLOBAL_AS uint8_t *) F.ycol;
+                        for (unsigned j = 0; j < spec_used; j++) { yc[S0 + j] = 0; yc[(unsigned) F.PA + S0 + j] = 0; }
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                /* the rows */
+                for (int j = 0; j < m; j++) {
+                    const int sid = TB + j, did = S0 + j;
+                    if (tid < 2) {
+                        const int l = tid;
+                        const int t = TREE(F, sid, l);
+                        TREE(F, did, l) = (short) (t >= TB ? t - shift : t);
+                        for (int e = 0; e < 6; e++) {
+                            const int d = INTO(F, sid, l, e);
+                            INTO(F, did, l, e) = (short) (d >= TB ? d - shift : d);
+                            WEIGHT(F, did, l, e) = WEIGHT(F, sid, l, e);
+                        }
+                        F.x[l * F.PA + did] = F.x[l * F.PA + sid]; F.y[l * F.PA + did] = F.y[l * F.PA + sid];
+                    } else if (tid == 2) {
+                        F.final_d[did] = F.final_d[sid]; F.level_of_state[did] = F.level_of_state[sid];
+                        F.domain_type[did] = F.domain_type[sid];
+                        const short p = F.pos[sid];
+                        F.pos[did] = p;
+                        if (p >= 0) F.pool_states[p] = (short) did;      /* the chain's list (the verifier kept its own) */
+                    }
+                    if (!F.domain_type[sid]) continue;                   /* an auxiliary state: no tables (uniform) */
+                    for (int i = tid; i < F.NI; i += B) F.img[(size_t) did * F.NI + i] = F.img[(size_t) sid * F.NI + i];
+                    if (tid < 32) F.imgT[(size_t) tid * F.P + did] = F.imgT[(size_t) tid * F.P + sid];
+                    for (int q = 0; q < F.NL; q++) {
+                        const float *Gs = GRAM(F, q) + GROW(sid, F.P);
+                        float *Gd = GRAM(F, q) + GROW(did, F.P);
+                        for (int t = tid; t < S0; t += B) Gd[t] = Gs[t];
+                        if (tid <= j) Gd[S0 + tid] = Gs[TB + tid];
+                        if (tid == 0) F.diag[(size_t) q * F.P + did] = F.diag[(size_t) q * F.P + sid];
+                    }
+                }
+                __threadfence();
+                __syncthreads();
+                if (tid == 0)            /* the verifier has its ids back */
+                    __hip_atomic_store(&c->adopting, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else if (spec_act == 2) {
                 const unsigned slot = spec_slot;
                 if (tid == 0) sl_keep = sh.sl;
@@ -3335,6 +3453,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                     __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     sh.sl.epoch++;                        /* ... and its verifier should drop it */
                     __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    /* ... before the search here appends a state: rows from this state count on, read by a
+                     * search that has not looked at the epoch yet, would change under it */
+                    while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);
                 }
                 __syncthreads();
                 /* the checkpoint was taken with the block's tables done.  In a buffer of the ring they still
@@ -3385,7 +3506,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         }
         __syncthreads();
 #if FC_SPEC
-        if (tid == 0 && role && (++sh.sl.ops & 7u) == 0
+        if (tid == 0 && role && (++sh.sl.ops & 1u) == 0
             && __hip_atomic_load(&F.spec->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh.sl.epoch) {
             sh.sl.abort = 1; sh.op = OP_DONE;         /* the chain has gone back behind this block */
         } else
@@ -3412,16 +3533,41 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #if FC_SPEC
     if (!role) break;
     __syncthreads();
+    /* A search of a block the chain has dropped meanwhile may get here without having looked at the epoch
+     * (it does every few operations): its result slot is the slot of a LATER block by now -- it must not
+     * write there.  (A return raises the epoch long before the later block's own result can be written:
+     * what still slips through between this look and the copy lands first and is overwritten.) */
+    if (tid == 0 && !sh.sl.abort
+        && __hip_atomic_load(&F.spec->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sh.sl.epoch) sh.sl.abort = 1;
+    __syncthreads();
+    if (!sh.sl.abort && sh.sl.verdict == 3) {            /* uniform: this workgroup's state, for the chain to take over */
+        /* (a buffer per verifier, behind the checkpoint slots: nobody else ever writes it, and this workgroup
+         * not again before the chain has read it -- see the wait below) */
+        uint4 *dst = (uint4 *) (SPEC_SLOTS(F.spec) + (size_t) (FC_SPEC_W + (role - T - 1)) * SPEC_STRIDE);
+        for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) dst[i] = ((const uint4 *) &sh)[i];
+        __threadfence();                                 /* + the rows of the states the search has appended */
+        __syncthreads();
+    }
     if (tid == 0) {
         if (!sh.sl.abort) {
-            /* (seq + 1) << 8 | ids the search used << 2 | verdict */
+            /* (seq + 1) << 11 | verifier << 8 | ids the search used << 2 | verdict */
             unsigned used = 0;
             while (used < FC_SPEC_TEMPS && F.level_of_state[sh.gap_hi + (int) used] != 0) used++;
             __hip_atomic_store(&F.spec->verdict[task_seq % FC_SPEC_W],
-                               ((task_seq + 1) << 8) | (used << 2) | (unsigned) sh.sl.verdict,
+                               ((task_seq + 1) << 11) | ((role - T - 1) << 8) | (used << 2) | (unsigned) sh.sl.verdict,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sh.sl.busy) { __threadfence(); atomicSub(&F.spec->busy, 1u); }      /* its rows are written */
+        if (!sh.sl.abort && sh.sl.verdict == 3) {
+            /* the rows of the states this search appended wait under this workgroup's ids for the chain to
+             * move them: no new search (it would write the same ids) before the chain has -- it raises the
+             * epoch when it is done with them, as it does when it drops the block for another reason */
+            while (__hip_atomic_load(&F.spec->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == sh.sl.epoch
+                   && __hip_atomic_load(&F.spec->committed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= task_seq
+                   && !__hip_atomic_load(&F.spec->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))
+                __builtin_amdgcn_s_sleep(16);
+            while (__hip_atomic_load(&F.spec->adopting, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(16);
+        }
     }
     }
     if (role) {
@@ -3435,7 +3581,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         __hip_atomic_store(&c->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         c->n_tasks = sh.sl.n_tasks; c->n_confirmed = sh.sl.n_confirmed; c->n_wrong = sh.sl.n_wrong;
         c->n_timeout = sh.sl.n_timeout; c->n_inline = sh.sl.n_inline; c->t_wait = sh.sl.t_wait;
-        c->n_tab_used = sh.sl.n_tab_used; c->n_tab_missed = sh.sl.n_tab_missed;
+        c->n_tab_used = sh.sl.n_tab_used; c->n_tab_missed = sh.sl.n_tab_missed; c->n_adopted = sh.sl.n_adopted;
     }
 #endif
     if (tid == 0) {
@@ -3464,6 +3610,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         F.states = sh.states;
         F.lc_min_out = sh.lc_min;
         F.status = sh.failed ? sh.failed : FC_OK;
+#if FC_SPEC
+        if (spec_bad) F.status = 128 + spec_bad;
+#endif
     }
     if (F.pack_dst) {                         /* the automaton for the host writer, packed */
         const uint4 *src = (const uint4 *) F.pack_src;

@@ -43,6 +43,8 @@ typedef struct fiasco_amd_stats {
     unsigned long long spec_frames, spec_tasks, spec_confirmed, spec_wrong, spec_timeout, spec_inline, spec_wait;
     /* blocks whose <sub-block, state> tables a table worker had ready for the chain / had not */
     unsigned long long spec_tab_used, spec_tab_missed;
+    /* wrong guesses after which the chain took over the verifier's state instead of searching the block again */
+    unsigned long long spec_adopted;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

@@ -78,7 +78,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    gpu = fiasco_amd.library()
+    gpu = fiasco_amd.Library(os.environ["FIASCO_AMD_LIB"]) if os.environ.get("FIASCO_AMD_LIB") else fiasco_amd.library()
     ora = fiasco_amd.Library(os.path.join(os.path.dirname(fiasco_amd.LIB_PATH), "..", "oracle", "liboracle_fiasco.so"))
     gpu.set_verbosity(0); ora.set_verbosity(0)
     bad = 0

@@ -25,8 +25,8 @@ for mode in modes:
     b = fiasco_amd.Batch(lib, frames, 20.0, opt)
     for rep in range(2):
         lib.reset_stats(); out = b.encode(); st = lib.get_stats()
-    print("%dx%d n=%d mode=%s: kernel %.3f s %.1f frames/s | spec frames %d tasks %d wrong %d inline %d wait %.2f s tables %d/%d"
-          % (w, h, n, mode, st.kernel_ms / 1e3, n / (st.kernel_ms / 1e3), st.spec_frames, st.spec_tasks, st.spec_wrong,
+    print("%dx%d n=%d mode=%s: kernel %.3f s %.1f frames/s | spec frames %d tasks %d wrong %d (taken over %d) inline %d wait %.2f s tables %d/%d"
+          % (w, h, n, mode, st.kernel_ms / 1e3, n / (st.kernel_ms / 1e3), st.spec_frames, st.spec_tasks, st.spec_wrong, st.spec_adopted,
              st.spec_inline, st.spec_wait / 1e8, st.spec_tab_used, st.spec_tab_missed), flush=True)
     if any(o is None for o in out): print("   ERROR", lib.error_message())
     if ref is None: ref = out

@@ -156,6 +156,7 @@ def small_launches(lib, opt, uniq, w, h):
             ent[key] = {"seconds": best, "frames_per_s": len(frames) / best,
                         "workgroups_per_frame_launches": int(st.spec_frames), "identical_streams": out == ref,
                         "blocks_confirmed": int(st.spec_confirmed), "blocks_sent_back": int(st.spec_wrong),
+                        "blocks_taken_over_from_the_verifier": int(st.spec_adopted),
                         "blocks_searched_by_the_chain": int(st.spec_inline)}
         o.delete()
         if big:

@@ -624,7 +624,7 @@ static void spec_block_list(const DevFrame &F, std::vector<uint16_t> &out)
     }
 }
 
-static int spec_groups(size_t frames, int cus, bool big_frames)
+static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only)
 {
     const char *e = getenv("FIASCO_AMD_SPEC");
     if (e && atoi(e) <= 1) return 0;
@@ -638,13 +638,23 @@ static int spec_groups(size_t frames, int cus, bool big_frames)
         if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
         return G >= 2 ? (int) G : 0;
     }
-    /* by default only while every workgroup has a CU to itself (measured, 1080p: 1 frame 3 x, 16
-     * frames 2.7 x, 64 frames (4 workgroups each) 1.7 x, 85 frames (3 each) 1.4 x the rate of one wide
-     * workgroup per frame; with two workgroups per CU the verifiers take from the chains what they
-     * give, with four the launch is slower) and with at least two verifiers per chain (one keeps it
-     * waiting: slower than no speculation at all) */
+    /* by default a CU per workgroup while the frames leave five or more to each (measured, 1080p: 1 frame
+     * 3.3 x, 16 frames 2.9 x the rate of one wide workgroup per frame; more workgroups than that per frame
+     * and CU are slower: 48 frames x 6 on 256 CUs 89 frames/s, x 5 93), and at least two verifiers per
+     * chain (one keeps it waiting: slower than no speculation at all) */
     size_t G = (size_t) cus / frames;
     if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
+    /* Fewer than five: the third verifier and the table worker are worth more than a CU of one's own,
+     * and three workgroups per frame beat one for as long as the chip holds them side by side -- 256-thread
+     * build only, every workgroup resident (3 per CU: 12 waves, 84 KB LDS).  1080p frames/s, one wide
+     * workgroup per frame -> this: 56 frames 86 (x 4) -> 102 (x 5), 64: 98 (x 4) -> 113 (x 5), 80: 97 (x 3)
+     * -> 114 (x 4), 96: 75 -> 132 (x 4), 128: 100 -> 140 (x 3), 160: 124 -> 168, 200: 155 -> 182, 256: 197 ->
+     * 213.  (64 x 6: 101; 4 without a table worker: 80 frames 97, 64 frames 89.) */
+    if (narrow_only && !big_frames && G < 5 && occ >= 3) {
+        if (4 * 5 * frames <= 5 * (size_t) cus) G = 5;             /* 1.25 workgroups per CU */
+        else if (2 * 4 * frames <= 3 * (size_t) cus) G = 4;        /* 1.5 */
+        else if (frames <= (size_t) cus) G = 3;                    /* 3 */
+    }
     /* 4K frames (the 1024-thread build; tables of megabytes per block): more than half the CUs busy
      * with them and they slow each other down -- 32 frames: 7.2 frames/s with 8 workgroups each, 7.9
      * with 6, 9.1 with 4 */
@@ -954,7 +964,16 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         int dev = 0, ncu = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        specG = spec_groups(n, ncu, n > 0 && jobs[0].image && (jobs[0].image->width > 2048 || jobs[0].image->height > 2048));
+        /* every frame for the 256-thread build of the speculating kernel?  (several of its workgroups fit a CU) */
+        bool narrow_only = n > 0;
+        for (unsigned i = 0; i < n && narrow_only; i++) {
+            const fa_cparams *cp = &jobs[i].cp;
+            if (!jobs[i].image) { narrow_only = false; break; }
+            const unsigned bw = fa_width_of_level(cp->lc_max_level), bh = fa_height_of_level(cp->lc_max_level);
+            const size_t blocks = (size_t) ((jobs[i].image->width + bw - 1) / bw) * ((jobs[i].image->height + bh - 1) / bh);
+            if (needs_wide_variant(cp) || blocks + blocks * 3 / 8 + 64 + FC_SPEC_MAXG * FC_SPEC_TEMPS > 3072) narrow_only = false;
+        }
+        specG = spec_groups(n, ncu, n > 0 && jobs[0].image && (jobs[0].image->width > 2048 || jobs[0].image->height > 2048), narrow_only);
         S->specG = specG;
     }
     if (hipStreamCreate(&S->stream) != hipSuccess || hipEventCreate(&S->ev0) != hipSuccess

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_c_options_set_progress_meter", "fiasco_c_options_set_comment",
     "fiasco_c_options_set_title", "fiasco_calloc", "open_file", "fiasco_amd_set_limits",
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
-    "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fa_core_name", "fiasco_amd_set_device",
+    "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
     "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload",

@@ -83,6 +83,11 @@ static fiasco_amd_stats g_stats;
 
 extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out) { *out = g_stats; }
 extern "C" void fiasco_amd_reset_stats(void) { memset(&g_stats, 0, sizeof g_stats); }
+static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ);
+extern "C" int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int narrow_only, int occupancy)
+{
+    return spec_policy(frames, cus, big_frames != 0, narrow_only != 0, occupancy);
+}
 extern "C" const char *fa_core_name(void) { return "hip-gfx950"; }
 
 /* workgroups (= frames) of a kernel build that one CU holds at once, as the runtime computes it
@@ -624,6 +629,8 @@ static void spec_block_list(const DevFrame &F, std::vector<uint16_t> &out)
     }
 }
 
+static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ);
+
 static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only)
 {
     const char *e = getenv("FIASCO_AMD_SPEC");
@@ -638,6 +645,14 @@ static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only
         if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
         return G >= 2 ? (int) G : 0;
     }
+    return spec_policy(frames, cus, big_frames, narrow_only, occ);
+}
+
+/* workgroups per frame of a launch (0: one, no speculation): a function of its arguments alone
+ * (fiasco_amd_spec_workgroups, include/libfiasco_amd_hip.h) */
+static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ)
+{
+    if (!frames || cus < 1) return 0;
     /* by default a CU per workgroup while the frames leave five or more to each (measured, 1080p: 1 frame
      * 3.3 x, 16 frames 2.9 x the rate of one wide workgroup per frame; more workgroups than that per frame
      * and CU are slower: 48 frames x 6 on 256 CUs 89 frames/s, x 5 93), and at least two verifiers per

@@ -50,6 +50,13 @@ typedef struct fiasco_amd_stats {
 void fiasco_amd_get_stats(fiasco_amd_stats *out);
 void fiasco_amd_reset_stats(void);
 
+/* The launcher's choice for a launch of `frames` frames on a device with `cus` compute units: how many
+ * workgroups a frame gets (chain + table workers + verifiers, block-level speculation; 0 = one workgroup per
+ * frame).  `big_frames`: frames beyond 2048 pixels in a dimension (4K); `narrow_only`: every frame fits the
+ * 256-thread build (at most 3072 states with the verifiers' ids); `occupancy`: workgroups of that build a CU
+ * holds at once.  A pure function (no device needed); FIASCO_AMD_SPEC overrides it at run time. */
+int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int narrow_only, int occupancy);
+
 /* name of the hot-path backend linked into this library: "hip-gfx950" for the product,
  * "oracle-cpu" for the test-only oracle library (reference seam: codec/approx.h:24-27,
  * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */

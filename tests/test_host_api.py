@@ -30,6 +30,24 @@ def test_headers_and_symbol_list_agree():
     assert decl <= set(fiasco_amd.EXPORTED_SYMBOLS), decl - set(fiasco_amd.EXPORTED_SYMBOLS)
 
 
+def test_workgroups_per_frame_of_a_launch(product):
+    """The launcher's policy for small launches (a pure function, no device): a CU per
+    workgroup down to five per frame, then shared CUs -- 256-thread build only -- down to three per frame
+    and three per CU; 4K frames never share a CU and leave half the chip alone."""
+    f = product.L.fiasco_amd_spec_workgroups
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    narrow = lambda n: f(n, 256, 0, 1, 5)
+    assert [narrow(n) for n in (1, 16, 32, 36, 42, 51)] == [8, 8, 8, 7, 6, 5]
+    assert [narrow(n) for n in (52, 64, 65, 96, 97, 128, 256, 257, 1024)] == [5, 5, 4, 4, 3, 3, 3, 0, 0]
+    # frames that may need the 1024-thread build, or a build a CU holds only one of: a CU per workgroup
+    assert [f(n, 256, 0, 0, 5) for n in (51, 64, 85, 86)] == [5, 4, 3, 0]
+    assert [f(n, 256, 0, 1, 1) for n in (64, 85, 86)] == [4, 3, 0]
+    # 4K: at most half the CUs once a frame has four workgroups
+    assert [f(n, 256, 1, 0, 1) for n in (1, 8, 16, 32, 64, 85, 86)] == [8, 8, 8, 4, 4, 3, 0]
+    assert f(0, 256, 0, 1, 5) == 0 and f(4, 0, 0, 1, 5) == 0
+
+
 def test_no_oracle_in_product():
     """The product library must not link or contain the CPU oracle."""
     out = subprocess.run(["nm", "-D", fiasco_amd.LIB_PATH], capture_output=True, text=True).stdout

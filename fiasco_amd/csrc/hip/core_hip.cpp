@@ -392,7 +392,7 @@ extern "C" void fiasco_amd_release_memory(void)
 /* ------------------------------------------------------------------ layout */
 
 struct Layout {
-    size_t gram, gcol, diag, ipis, cmax, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
+    size_t gram, gcol, diag, ipis, d5, d4, img, imgT, imgT4, norms, num, den, est, ipdo, used, tree, into, weight,
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
@@ -414,7 +414,6 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(gcol, tri ? (size_t) NL * FC_TRI_HOT * P * 4 : 0);      /* columns of the first states as rows (frame_coder.h) */
     CARVE(diag, (size_t) NL * P * 4);
     CARVE(ipis, (size_t) NS * P * 4);
-    CARVE(cmax, (size_t) NS * (P / 64) * 4);        /* per heap slot and 64-state block (frame_coder.hip op_ipis) */
     CARVE(d5, (size_t) NA * P * 4);
     CARVE(d4, low ? (size_t) 2 * NA * P * 4 : 0);
     CARVE(img, (size_t) P * NI * 4);
@@ -732,7 +731,6 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.pix16 = (const int16_t *) (base + L.pix16);
     F.gram = (float *) (base + L.gram); F.diag = (float *) (base + L.diag);
     F.ipis = (float *) (base + L.ipis); F.d5 = (float *) (base + L.d5);
-    F.cmax = (float *) (base + L.cmax);
     F.gcol = (float *) (base + L.gcol);
     F.d4 = (float *) (base + L.d4); F.imgT4 = (float *) (base + L.imgT4);
     F.img = (float *) (base + L.img); F.imgT = (float *) (base + L.imgT);
@@ -1464,7 +1462,7 @@ static bool launch_wave(Staged *S)
         for (size_t i = 0; i < nall; i++) {
             const DevFrame &F = hf[first_all + i];
             const size_t P = (size_t) F.P;
-            priv[i] = align_up((size_t) F.NS * P * 4, 256) + align_up((size_t) F.NS * (P / 64) * 4, 256)
+            priv[i] = align_up((size_t) F.NS * P * 4, 256)
                       + align_up((size_t) F.NA * P * 4, 256) + 3 * align_up(P * 4, 256) + align_up((size_t) FC_MAXED * P * 4, 256)
                       + align_up(P, 256) + align_up((P + 8) * 2, 256) + align_up(((size_t) F.PA + 8) * 4, 256);
             need += priv[i] * (size_t) NV;
@@ -1502,7 +1500,6 @@ static bool launch_wave(Staged *S)
                     const size_t P = (size_t) C.P;
                     char *q = S->d_spec + o;
                     V.ipis = (float *) q;  q += align_up((size_t) C.NS * P * 4, 256);
-                    V.cmax = (float *) q;  q += align_up((size_t) C.NS * (P / 64) * 4, 256);
                     V.d5 = (float *) q;    q += align_up((size_t) C.NA * P * 4, 256);
                     V.num = (float *) q;   q += align_up(P * 4, 256);
                     V.den = (float *) q;   q += align_up(P * 4, 256);

@@ -15,7 +15,6 @@
  *    diag   [NL][P]    f32  Gram diagonal (matching-pursuit denominators)
  *    ipis   [NS][P]    f32  <range sub-block, state>, heap slot major
  *                           (reference ip_images_state, codec/cwfa.h:89, is state major)
- *    cmax   [NS][P/64] f32  per slot and 64-state block: max of ipis^2 / diag (first-step bounds)
  *    d5     [NA][P]    f32  level-images_level dots of the current block, address major
  *    img    [P][NI]    f32  state images levels 0..images_level (reference layout)
  *    imgT   [2^il][P]  f32  level-images_level slice of img, pixel major (coalesced dots)
@@ -89,9 +88,6 @@ typedef struct DevFrame {
                             * chooses first is state 0 in 41 % and one of the first eight in 46 % of the searches
                             * (measured with the oracle); their sweep reads this row instead of one 4-byte gather
                             * (a whole HBM line) per candidate */
-    float   *cmax;         /* [NS][P / 64] largest <range, state>^2 / <state, state> of each 64-state block, per
-                            * heap slot of the current pixel block: the first step of a search starts its
-                            * ordered scan from these (mp_sl.inc) instead of sweeping the dictionary */
     float   *d4, *imgT4;   /* level images_level-1 twins of d5 / imgT (block levels down to 4) */
     float   *num, *den, *est, *ipdo;
     uint8_t *used;

@@ -126,13 +126,28 @@
 #ifndef SPEC_THR
 #define SPEC_THR 1.2f          /* FC_SPEC: see SpecLocal.mlc */
 #endif
-#if FC_SPEC && (FC_VARIANT_BIG || (defined(FC_GRAM_TRI) && FC_GRAM_TRI))
-#error "FC_SPEC is a variant of the default geometry with full Gram tables (256 or 1024 threads)"
+/* FC_SPINE: left-spine batching (mp_wave.inc) -- the linear-combination searches of a node and of its
+ * chain of first children run at once, one per wave.  Bit-exact (the parked results are what the
+ * searches would have found: same models, same dictionary), but it does not pay: a wave on its own
+ * needs 3.4 x the time of the four waves together for one search, so a spine of three ranges costs what
+ * three searches cost (519 .. 572 frames/s against 549 on the bench batch).
+ * Kept as a build switch of the 256-thread default build for whoever wants to re-measure; off. */
+#ifndef FC_SPINE
+#define FC_SPINE 0
 #endif
-/* FC_SCAN_SL: the matching-pursuit scan recomputes a candidate from its table rows in every pass
- * (mp_sl.inc) instead of carrying it through the call in registers (mp_reg.inc) */
-#ifndef FC_SCAN_SL
-#define FC_SCAN_SL 0
+#if FC_SPINE && (FC_VARIANT_BIG || FC_VARIANT_WIDE || FC_SPEC)
+#error "FC_SPINE is a variant of the 256-thread default build"
+#endif
+#define FC_SPINE_W 4            /* ranges of a spine searched at once: one per wave of the 256-thread build */
+/* FC_BLKEST: the sweep of a matching-pursuit pass prices whole 64-state blocks at once where the position
+ * pricing is the same for every candidate of the block (mp_device.inc, stage1_block_price).  Exact as
+ * well, and also no gain (520 against 549 frames/s): from the second pass on a fifth of the blocks hold a
+ * breakpoint of the pricing and go the long way round anyway.  Off. */
+#ifndef FC_BLKEST
+#define FC_BLKEST 0
+#endif
+#if FC_BLKEST && (FC_VARIANT_BIG || FC_SPEC)
+#error "FC_BLKEST needs the default geometry without speculation (Sh::cum)"
 #endif
 /* FC_EST_RCP: the sweep's block minima are taken over a tight lower bound of the estimates
  * (reciprocal instead of division, stage1<.., LBQ> in mp_device.inc) */
@@ -142,9 +157,6 @@
 /* FC_MIN4: block minima of the register scan four slots at a time (interleaved DPP chains) */
 #ifndef FC_MIN4
 #define FC_MIN4 1
-#endif
-#ifndef FC_SL_NEXT_TOUCH
-#define FC_SL_NEXT_TOUCH 0
 #endif
 #define MAXED   FC_MAXED
 /* edges per label a state of this build can have (= max_elements the build accepts): the table
@@ -310,14 +322,30 @@ struct Sh {
     float    Q0, Q1;
     float    tb[2];                /* default build: tree_bits (LEAF, CHILD) of the level being approximated (mp_tables) */
     MPState  mp;
+#if FC_SPINE
+    /* left-spine batching (mp_wave.inc): search state and result of the range w levels below the top node
+     * of the current spine, with the log2 table of its level's coefficient context and its tree prices;
+     * slot 0 is the top node itself.  spine_n ranges were searched when the node at stack depth spine_top
+     * was entered; spine_next is the depth of the next one the partition search may pick up; spine_use
+     * (lane 0, per OP_APPROX) is the slot of the node being approximated, 0 = search it now. */
+    struct SpineSlot { MPState mp; double lglv[16], lglv_m1; float tb[2]; } spine[FC_SPINE_W];
+    int      spine_top, spine_n, spine_next, spine_use;
+    /* ticks (100 MHz) and calls of OP_APPROX by kind: 0 a spine of K >= 2 ranges, 1 a parked result picked
+     * up, 2 one range searched by the whole workgroup; [3] = ranges searched in spines (DevFrame.dbg) */
+    unsigned long long spine_t[3];
+    unsigned spine_c[4];
+#endif
 #if FC_VARIANT_BIG
     MPState  mp_keep;              /* best result so far of a call with retries */
     int      apx_stage, apx_it, apx_more;   /* retry plan of approximate_range (lane 0) */
 #endif
     float    blockmin[NBLOCKMIN];
-#if FC_SCAN_SL
-    /* mp_sl.inc: (estimate, costs) of the candidates of the blocks of a round, per round parity */
-    float    slx[2][2][B / 64][64];
+#if FC_BLKEST
+    /* cum[b] = pool position of the first pool state with id >= 64 b (states enter the rle pool in id
+     * order, codec/domain-pool.c:832-852): the positions of block b are the run [cum[b], cum[b + 1]), the
+     * last block's ends at pool.n.  Written when state 64 b is stored (store_new_state); an entry is
+     * rewritten whenever that id is created again after a removal, so it always fits the dictionary. */
+    unsigned short cum[NBLOCKMIN + 2];
 #endif
     float    pixels[FC_PIXELS];
     float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
@@ -714,64 +742,9 @@ __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRow
     }
 }
 
-/* maximum over the 64 lanes of a wave on the DPP path, result in LANE 63 (see wave_min_l63 in
- * mp_device.inc); the values here are >= 0 */
-__device__ __forceinline__ float wave_max_l63(float v)
-{
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return v;
-}
-
-/* four independent maxima at once: the four DPP chains are interleaved, so the two wait states
- * between a VALU write and a DPP read of the same register are filled with the other chains */
-__device__ __forceinline__ void wave_max4_l63(float &a, float &b, float &c, float &d)
-{
-#define MAX4_STEP(ctl)                                                     \
-        "v_max_f32_dpp %0, %0, %0 " ctl "\n\t"                             \
-        "v_max_f32_dpp %1, %1, %1 " ctl "\n\t"                             \
-        "v_max_f32_dpp %2, %2, %2 " ctl "\n\t"                             \
-        "v_max_f32_dpp %3, %3, %3 " ctl "\n\t"
-    asm volatile(
-        "s_nop 1\n\t"
-        MAX4_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-        MAX4_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        MAX4_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-        MAX4_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        MAX4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        MAX4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#undef MAX4_STEP
-}
-
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
- * onto zero, which is the reference's accumulation order onto its zeroed slots.
- *
- * Default build, luminance: the same pass leaves in F.cmax, per slot and 64-state block, the
- * largest num^2 / den a candidate of the block can bring to the FIRST step of a search of that
- * sub-block (num = the entry just computed, den = the Gram diagonal of the slot's level; 0 for a
- * state that cannot be a candidate).  The stage-1 estimate of a candidate falls with that
- * quotient and rises with its rate terms, every rounding step is monotone: (smallest rate
- * terms) x price + error - cmax is a lower bound of every estimate in the block, and a lower
- * bound is all the ordered scan needs to decide which blocks it may skip -- the first step of a
- * call does not sweep the dictionary at all (mp_sl.inc).  Blocks are recomputed whole: `from` is
- * rounded down to a block boundary (the lanes are there anyway; the entries of the older states
- * come out as they are). */
+ * onto zero, which is the reference's accumulation order onto its zeroed slots. */
 __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level;
@@ -780,16 +753,6 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
     level = __builtin_amdgcn_readfirstlane(level); from = __builtin_amdgcn_readfirstlane(from);
     GLOBAL_AS float *const ipis = uniform_ptr(ACT_IPIS(F, sh));
     GLOBAL_AS const float *const d5 = uniform_ptr((const float *) ACT_D5(F, sh));
-#if FC_SCAN_SL && !FC_VARIANT_BIG
-    const bool bounds = !sh.band;                      /* uniform */
-    GLOBAL_AS float *const cmax = uniform_ptr(F.cmax);
-    GLOBAL_AS const float *const diag = uniform_ptr((const float *) F.diag);
-    GLOBAL_AS const int16_t *const pos = uniform_ptr((const int16_t *) F.pos);
-    const int NB = P >> 6, lane = tid & 63;
-    if (bounds) from &= ~63;
-#else
-    const bool bounds = false;
-#endif
     AutoTabs T;
     auto_tabs(F, T);
     for (int lv = il + 1; lv <= level; lv++) {
@@ -799,24 +762,16 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
         int adr0 = address << delta;
         GLOBAL_AS const float *src0 = (lv == il + 1) ? d5 + (size_t) (adr0 * 2) * P
                                                      : ipis + (size_t) (slot0 * 2 + 1) * P;
-#if FC_SCAN_SL && !FC_VARIANT_BIG
-        const float rsize = 1.0f / (float) (1u << lv);
-        const unsigned qrow = (unsigned) ((lv - F.gl0) * P);
-#endif
         /* the rows of the NEXT state of this lane are requested before the gathers of the
-         * current one are waited for (one memory round trip per state instead of two).  With the
-         * bounds a wave stays together until its whole 64-state block is done: lanes past the
-         * last state run along with an empty term list. */
+         * current one are waited for (one memory round trip per state instead of two) */
         int s = from + tid;
-        const int send = bounds ? ((states + 63) & ~63) : states;
         EdgeRows nx;
         if (s < states) load_edge_rows(T, s, nx);
-        for (; s < send; s += B) {
+        for (; s < states; s += B) {
             const EdgeRows cur = nx;
-            const bool valid = s < states;
             if (s + B < states) load_edge_rows(T, s + B, nx);
-            const bool tabled = valid && cur.dt && !DEAD(sh, s);
-            if (!bounds && !tabled) continue;
+            const bool tabled = cur.dt && !DEAD(sh, s);
+            if (!tabled) continue;
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
              * of a group of slots are in flight together (the chain is latency bound). */
@@ -826,10 +781,10 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
 #pragma unroll
             for (int l = 0; l < 2; l++) {
                 int k = cur.tree[l];
-                msk[l] = tabled && k != RANGE_ ? 1u : 0u;
-                idx[l][0] = tabled && k != RANGE_ ? k : 0;
+                msk[l] = k != RANGE_ ? 1u : 0u;
+                idx[l][0] = k != RANGE_ ? k : 0;
                 wt[l][0] = 1.0f;
-                bool live = tabled;
+                bool live = true;
 #pragma unroll
                 for (int e = 0; e < FC_MAXE; e++) {
                     live = live && cur.rd[l][e] != NOEDGE;
@@ -838,20 +793,6 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
-#if FC_SCAN_SL && !FC_VARIANT_BIG
-            /* can the state be a candidate at this level at all (codec/approx.c:360-377)?  Its
-             * Gram diagonal and pool position: one read each per level and state */
-            /* rden: an UPPER bound of 1 / den is all that is needed (the table holds upper bounds):
-             * the hardware reciprocal (1 ulp) times (1 + 2^-21) instead of a division per slot */
-            float rden = 0.0f;
-            if (bounds) {
-                const unsigned us = (unsigned) (valid ? s : 0);
-                const float den = ldg(diag, qrow + us);
-                const bool cand = tabled && ldg(pos, us) >= 0 && !(den * rsize < MIN_NORM);
-                rden = cand ? __builtin_amdgcn_rcpf(den) * 1.00000047683715820312f : 0.0f;
-            }
-            float cb[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#endif
             constexpr int JG = 4;          /* slots per group: 4 x 2 x (FC_MAXE + 1) gathers in flight per lane (8: -5 %) */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
                 float v[JG][2][FC_MAXE + 1];
@@ -879,20 +820,8 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                         for (int i = 1; i <= FC_MAXE; i++)
                             if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
                     }
-                    if (tabled) stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
-#if FC_SCAN_SL && !FC_VARIANT_BIG
-                    cb[jj] = acc * acc * rden;
-#endif
+                    stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
                 }
-#if FC_SCAN_SL && !FC_VARIANT_BIG
-                if (bounds) {                                       /* uniform */
-                    wave_max4_l63(cb[0], cb[1], cb[2], cb[3]);
-#pragma unroll
-                    for (int jj = 0; jj < JG; jj++)
-                        if (j0 + jj < cnt && lane == 63)
-                            stg(cmax, (unsigned) ((slot0 + j0 + jj) * NB + (s >> 6)), cb[jj]);
-                }
-#endif
             }
         }
         __syncthreads();
@@ -1903,6 +1832,9 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
     GLOBAL_AS float *const weight = (GLOBAL_AS float *) sh.par.at_weight, *const fin = (GLOBAL_AS float *) sh.par.at_final;
     GLOBAL_AS uint16_t *const xs = (GLOBAL_AS uint16_t *) sh.par.at_x, *const ys = (GLOBAL_AS uint16_t *) sh.par.at_y;
     short p = -1;
+#if FC_BLKEST
+    if ((s & 63) == 0 && (s >> 6) <= NBLOCKMIN) sh.cum[s >> 6] = sh.pool.n;
+#endif
     if (!aux && sh.pool.n < sh.pool.max_domains) {
         p = (short) sh.pool.n;
         pool[sh.pool.n++] = (short) s;
@@ -2065,6 +1997,10 @@ __device__ void push_root(DevFrame &__restrict__ F, Sh &__restrict__ sh, int y_s
     r.max_costs = MAXCOSTS;
     r.y_state = y_state;
     r.phase = PH_ENTER;
+#if FC_SPINE
+    sh.spine_n = 0; sh.spine_use = 0;
+    if (sh.band == 0) { for (int k = 0; k < 3; k++) sh.spine_t[k] = 0; for (int k = 0; k < 4; k++) sh.spine_c[k] = 0; }
+#endif
 #if FC_SPEC
     r.ckpt = 0;
 #endif
@@ -2371,6 +2307,21 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 fr.lrange.nd_tree_bits = 0; fr.lrange.nd_weights_bits = 0; fr.lrange.prediction = 0;
                 fr.lrange.mv_tree_bits = fr.try_pred == 2 ? 1.0f : 0.0f;   /* mc allowed but not used */
                 fr.lrange.mv_coord_bits = 0;
+#endif
+#if FC_SPINE
+                {   /* Is this range the next one on the spine that was searched when its top node was entered
+                     * (mp_wave.inc)?  It is iff the search has descended from the last range picked up into
+                     * its FIRST child: models, dictionary and tree model are then what the spine's search saw
+                     * (codec/subdivide.c:226-237 restores them before :303-310 recurses).  Anything else
+                     * drops what is parked. */
+                    int use = 0;
+                    if (sh.spine_n) {
+                        if (sp == sh.spine_next && sp - sh.spine_top < sh.spine_n && sh.st[sp - 1].label == 0) {
+                            use = sp - sh.spine_top; sh.spine_next = sp + 1;
+                        } else sh.spine_n = 0;
+                    }
+                    sh.spine_use = use;
+                }
 #endif
                 sh.op = OP_APPROX;
                 return 0;
@@ -3106,6 +3057,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         for (int i = 0; i <= MAXED; i++) { m.count[i] = 1; m.total++; }
         m.n = 0; m.max_domains = (unsigned short) F.pool_max; m.y_index = 0;
         m.d0_index = 0; m.d0_yindex = 0; m.d0_n = 0;
+#if FC_BLKEST
+        sh.cum[0] = 0;
+#endif
         for (int s = 0; s < F.basis_states; s++) {
             F.pos[s] = -1;
             if ((F.domain_type[s] & 2) && m.n < m.max_domains) {
@@ -3601,6 +3555,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     }
 #ifdef FC_PM
     if (tid == 0) for (int k = 0; k < 8; k++) F.dbg[k] = sh.pm[k];
+#elif FC_SPINE && !defined(FC_SERIAL_PROFILE) && !defined(FC_BLKEST_CHECK)
+    if (tid == 0) {
+        for (int k = 0; k < 3; k++) { F.dbg[2 * k] = sh.spine_t[k]; F.dbg[2 * k + 1] = sh.spine_c[k]; }
+        F.dbg[6] = sh.spine_c[3];
+        /* which SIMD runs wave 0 (the serial lane): histogram over the frames of a launch, 16 bits per SIMD
+         * (HW_REG_HW_ID, bits 5:4) */
+        F.dbg[7] = 1ull << (16 * ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3));
+    }
 #endif
 #if FC_SPEC && !defined(FC_PM) && !defined(FC_SERIAL_PROFILE)
     if (tid == 0) { F.dbg[0] = tk[OP_SPEC_CKPT]; F.dbg[1] = 0; }   /* ticks of the chain in checkpoints, verdicts and returns */

@@ -2473,8 +2473,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
             tree_update_dev(sh, ML, !ch.prediction, ch.level, 1);     /* subdivide.c:371-372 */
 #else
+            /* (the second tree model, codec/subdivide.c:371-372, prices nothing without prediction and is
+             * not part of the default build's snapshots: not kept) */
             tree_update_dev(sh, ML, ch.tree != RANGE_, ch.level, 0);
-            tree_update_dev(sh, ML, 1, ch.level, 1);
 #endif
             fr.label = label + 1;
             phase = fr.label < 2 ? PH_CHILD : PH_DECIDE;

@@ -120,6 +120,7 @@ def small_launches(lib, opt, uniq, w, h):
     import fiasco_amd
     import synth
     res = {}
+    os.environ["FIASCO_AMD_DEBUG"] = "1"      # FIASCO_AMD_SPEC below is a developer switch of the library
     # BASELINE config 3 (colour 1080p: needs the declared limits extension) and one 4K frame
     colour = [synth.ppm_bytes(synth.synth_color_k(w, h))]
     gray4k = [synth.pgm_bytes(synth.synth(3840, 2160, 1234))]
@@ -300,10 +301,10 @@ def main():
         # them: taken from one pass with one workgroup per frame.
         alg_override = None
         if lib.get_stats().spec_frames:
-            os.environ["FIASCO_AMD_SPEC"] = "0"
+            os.environ["FIASCO_AMD_DEBUG"] = "1"; os.environ["FIASCO_AMD_SPEC"] = "0"
             b1 = fiasco_amd.Batch(lib, frames, 20.0, opt)
             lib.reset_stats(); b1.encode(); s1 = lib.get_stats(); b1.free()
-            os.environ.pop("FIASCO_AMD_SPEC")
+            os.environ.pop("FIASCO_AMD_SPEC"); os.environ.pop("FIASCO_AMD_DEBUG")
             alg_override = float(s1.bytes_mp + s1.bytes_img + s1.bytes_gram) / max(s1.launches, 1)
         # ---- loop A: inputs resident in HBM ----
         barrier()

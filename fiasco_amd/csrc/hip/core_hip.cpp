@@ -23,6 +23,17 @@
 #include "frame_coder.h"
 #include "libfiasco_amd_hip.h"
 
+/* Developer and test switches (FIASCO_AMD_SPEC, _NO_WIDE, _FORCE_TRI, _CAP_GUESS, _QUEUE_SLABS, _TRACE, ...)
+ * are honoured only when FIASCO_AMD_DEBUG is set to something other than 0: a drop-in library must not
+ * change its behaviour because of a stray variable in a user's environment.  What a user may set without
+ * it: FIASCO_AMD_CACHE (cache directory), FIASCO_AMD_NO_LOG2_TABLE (encode without the log2 correction
+ * table), FIASCO_AMD_DEVICES (devices of the multi-device batch entries, fa_multi.cpp). */
+extern "C" const char *fa_knob(const char *name)
+{
+    const char *d = getenv("FIASCO_AMD_DEBUG");
+    return d && *d && strcmp(d, "0") != 0 ? getenv(name) : nullptr;
+}
+
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
 extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
@@ -132,8 +143,11 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
  * argument is a float in (0, 1] (and 1 - p is one in [0, 1)), so the claim can be checked
  * exhaustively: this entry evaluates log2((double) p) on the device for all floats of an
  * exponent range and compares the doubles bit for bit with glibc's on the host. */
+#include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <unistd.h>
 
 __global__ void selftest_log2_kernel(unsigned first_bits, unsigned n, double *out, const unsigned *keys,
@@ -175,7 +189,7 @@ static void *l2_thread(void *arg)
 
 /* the table of host log2 values the kernels use (DevFrame.l2_*), per process */
 struct Log2Patch { unsigned *d_keys = nullptr; double *d_vals = nullptr; unsigned mask = 0; int device = -1;
-                   unsigned long long entries = 0; bool tried = false; };
+                   unsigned long long entries = 0; bool tried = false, ok = false; };
 static Log2Patch g_l2;
 static unsigned long long g_l2_max_ulp;      /* largest distance seen by the last comparisons, in ulps */
 extern "C" unsigned long long fiasco_amd_selftest_log2_max_ulp(void) { return g_l2_max_ulp; }
@@ -246,13 +260,14 @@ extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsign
     return log2_compare(exp_lo, exp_hi, false, n_checked, n_double, n_float, first_bad, nullptr);
 }
 
-static void log2_patch_build(void);
+static bool log2_patch_build(void);
+static char g_l2_err[200];
 
 /* the same comparison THROUGH the table the frame kernel uses: n_double must come out 0 */
 extern "C" int fiasco_amd_selftest_log2_patched(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
                                                 unsigned long long *n_double, unsigned long long *n_entries)
 {
-    log2_patch_build();
+    if (!log2_patch_build()) { fa_set_error("selftest: no log2 table on this device: %s", g_l2_err); return 0; }
     if (n_entries) *n_entries = g_l2.entries;
     if (!g_l2.d_keys && g_l2.entries) { fa_set_error("selftest: no log2 table on this device"); return 0; }
     return log2_compare(exp_lo, exp_hi, g_l2.d_keys != nullptr, n_checked, n_double, nullptr, nullptr, nullptr);
@@ -260,19 +275,62 @@ extern "C" int fiasco_amd_selftest_log2_patched(unsigned exp_lo, unsigned exp_hi
 
 /* Build (or load from the cache file) the table of this process: every float in (0, 1] whose
  * device log2 differs from the host's, with the host's value.  About a second of work the first
- * time on a box; the list (some 12 MB) is then kept in $FIASCO_AMD_CACHE (default /tmp) under a
- * name that carries the host libm's and the device's answers to a few probe arguments, and is
- * re-validated on load. */
-static void log2_patch_build(void)
+ * time on a box; the list (some 12 MB) is then kept in a per-user cache directory -- $FIASCO_AMD_CACHE,
+ * else $XDG_CACHE_HOME/fiasco_amd, else $HOME/.cache/fiasco_amd, /tmp only as the last resort -- under a
+ * name that carries the host libm's and the device's answers to a few probe arguments.  A cache file is
+ * taken only if its checksum fits and EVERY stored value is what this host's log2 computes now.
+ *
+ * Returns false -- with the reason in g_l2_err -- when the table is needed but could not be built or
+ * brought onto the device: 1 018 853 arguments differ between ocml and glibc, frames coded without
+ * the table could differ from the reference's streams, so fa_core_stage() fails them instead
+ * (FIASCO_AMD_NO_LOG2_TABLE=1 runs without the table on purpose). */
+
+static unsigned long long fnv64(const void *p, size_t n, unsigned long long h = 1469598103934665603ull)
+{
+    const unsigned char *c = (const unsigned char *) p;
+    for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 1099511628211ull;
+    return h;
+}
+
+static void mkdir_p(const char *dir)
+{
+    char tmp[512];
+    snprintf(tmp, sizeof tmp, "%s", dir);
+    for (char *q = tmp + 1; *q; q++)
+        if (*q == '/') { *q = 0; (void) mkdir(tmp, 0700); *q = '/'; }
+    (void) mkdir(tmp, 0700);
+}
+
+/* cache directory of this user; created if need be */
+static void l2_cache_dir(char *out, size_t n)
+{
+    const char *e;
+    if ((e = getenv("FIASCO_AMD_CACHE")) && *e) snprintf(out, n, "%s", e);
+    else if ((e = getenv("XDG_CACHE_HOME")) && *e) snprintf(out, n, "%s/fiasco_amd", e);
+    else if ((e = getenv("HOME")) && *e) snprintf(out, n, "%s/.cache/fiasco_amd", e);
+    else snprintf(out, n, "/tmp");
+    mkdir_p(out);
+    if (access(out, W_OK) != 0) snprintf(out, n, "/tmp");
+}
+
+static bool log2_patch_build(void)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    if (g_l2.tried && g_l2.device == dev) return;
+    g_l2_err[0] = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_l2_err, sizeof g_l2_err, "no current HIP device"); return false; }
+    if (g_l2.tried && g_l2.device == dev) {
+        if (!g_l2.ok) snprintf(g_l2_err, sizeof g_l2_err, "an earlier attempt on this device failed");
+        return g_l2.ok;
+    }
     if (g_l2.d_keys) { (void) hipFree(g_l2.d_keys); (void) hipFree(g_l2.d_vals); g_l2 = Log2Patch(); }
-    g_l2.tried = true; g_l2.device = dev;
-    if (getenv("FIASCO_AMD_NO_LOG2_TABLE")) return;
+    g_l2.tried = true; g_l2.device = dev; g_l2.ok = false;
+    if (getenv("FIASCO_AMD_NO_LOG2_TABLE")) { g_l2.ok = true; return true; }
+    if (fa_knob("FIASCO_AMD_FAIL_LOG2_TABLE")) {                    /* tests: what a failed build looks like */
+        snprintf(g_l2_err, sizeof g_l2_err, "failure requested by FIASCO_AMD_FAIL_LOG2_TABLE");
+        return false;
+    }
     std::vector<std::pair<unsigned, double>> list;
-    char path[512];
+    char path[600];
     {
         /* fingerprint: host libm on a few awkward arguments + device name */
         hipDeviceProp_t prop;
@@ -287,20 +345,25 @@ static void log2_patch_build(void)
             for (const char *c = prop.gcnArchName; *c; c++) fp = (fp ^ (unsigned char) *c) * 1099511628211ull;
         int rt = 0; (void) hipRuntimeGetVersion(&rt);
         fp = (fp ^ (unsigned) rt) * 1099511628211ull;
-        const char *dir = getenv("FIASCO_AMD_CACHE");
-        snprintf(path, sizeof path, "%s/fiasco_amd_log2_%016llx.bin", dir && *dir ? dir : "/tmp", fp);
+        char dir[512];
+        l2_cache_dir(dir, sizeof dir);
+        snprintf(path, sizeof path, "%s/fiasco_amd_log2_%016llx.bin", dir, fp);
     }
     bool loaded = false;
     if (FILE *f = fopen(path, "rb")) {
-        unsigned long long hdr[2] = { 0, 0 };
-        if (fread(hdr, 8, 2, f) == 2 && hdr[0] == 0x32474f4c41464full && hdr[1] < (1ull << 26)) {
+        /* magic, entries, FNV-1a of the payload */
+        unsigned long long hdr[3] = { 0, 0, 0 };
+        if (fread(hdr, 8, 3, f) == 3 && hdr[0] == 0x33474f4c41464full && hdr[1] < (1ull << 26)) {
             list.resize((size_t) hdr[1]);
-            loaded = fread(list.data(), sizeof list[0], list.size(), f) == list.size();
-            /* the stored values must still be what this host computes */
-            for (size_t i = 0; loaded && i < list.size(); i += 1 + list.size() / 4096) {
-                float p; memcpy(&p, &list[i].first, 4);
-                double v = log2((double) p);
-                if (memcmp(&v, &list[i].second, 8) != 0) loaded = false;
+            loaded = fread(list.data(), sizeof list[0], list.size(), f) == list.size()
+                     && fgetc(f) == EOF
+                     && fnv64(list.data(), list.size() * sizeof list[0]) == hdr[2];
+            /* every stored value must still be what this host computes (a second of log2 calls
+             * at most: cheap next to trusting a file somebody else could have written) */
+            for (size_t i = 0; loaded && i < list.size(); i++) {
+                float pf; memcpy(&pf, &list[i].first, 4);
+                double v = log2((double) pf);
+                if (!(pf > 0.0f && pf <= 1.0f) || memcmp(&v, &list[i].second, 8) != 0) loaded = false;
             }
         }
         fclose(f);
@@ -308,18 +371,24 @@ static void log2_patch_build(void)
     }
     if (!loaded) {
         unsigned long long nd = 0;
-        if (!log2_compare(1, 127, false, nullptr, &nd, nullptr, nullptr, &list)) { list.clear(); return; }
-        char tmp[560];
-        snprintf(tmp, sizeof tmp, "%s.%d", path, (int) getpid());
-        if (FILE *f = fopen(tmp, "wb")) {
-            unsigned long long hdr[2] = { 0x32474f4c41464full, (unsigned long long) list.size() };
-            bool ok = fwrite(hdr, 8, 2, f) == 2 && fwrite(list.data(), sizeof list[0], list.size(), f) == list.size();
-            fclose(f);
-            if (!ok || rename(tmp, path) != 0) (void) remove(tmp);
+        if (!log2_compare(1, 127, false, nullptr, &nd, nullptr, nullptr, &list)) {
+            snprintf(g_l2_err, sizeof g_l2_err, "the comparison of the device's log2 with the host's did not run (%s)",
+                     hipGetErrorString(hipGetLastError()));
+            return false;
         }
+        char tmp[640];
+        snprintf(tmp, sizeof tmp, "%s.%d", path, (int) getpid());
+        int fd = open(tmp, O_WRONLY | O_CREAT | O_EXCL, 0600);
+        if (FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr) {
+            unsigned long long hdr[3] = { 0x33474f4c41464full, (unsigned long long) list.size(),
+                                          fnv64(list.data(), list.size() * sizeof list[0]) };
+            bool ok = fwrite(hdr, 8, 3, f) == 3 && fwrite(list.data(), sizeof list[0], list.size(), f) == list.size();
+            ok = fclose(f) == 0 && ok;
+            if (!ok || rename(tmp, path) != 0) (void) remove(tmp);      /* no cache: built again next time */
+        } else if (fd >= 0) close(fd);
     }
     g_l2.entries = list.size();
-    if (list.empty()) return;
+    if (list.empty()) { g_l2.ok = true; return true; }       /* the two logarithms agree everywhere: nothing to correct */
     unsigned slots = 1024;
     while (slots < 4 * list.size()) slots <<= 1;
     std::vector<unsigned> keys(slots, 0u);
@@ -329,17 +398,22 @@ static void log2_patch_build(void)
         while (keys[h]) h = (h + 1) & (slots - 1);
         keys[h] = list[i].first; vals[h] = list[i].second;
     }
-    if (hipMalloc((void **) &g_l2.d_keys, (size_t) slots * 4) != hipSuccess
-        || hipMalloc((void **) &g_l2.d_vals, (size_t) slots * 8) != hipSuccess
-        || hipMemcpy(g_l2.d_keys, keys.data(), (size_t) slots * 4, hipMemcpyHostToDevice) != hipSuccess
-        || hipMemcpy(g_l2.d_vals, vals.data(), (size_t) slots * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    hipError_t e;
+    if ((e = hipMalloc((void **) &g_l2.d_keys, (size_t) slots * 4)) != hipSuccess
+        || (e = hipMalloc((void **) &g_l2.d_vals, (size_t) slots * 8)) != hipSuccess
+        || (e = hipMemcpy(g_l2.d_keys, keys.data(), (size_t) slots * 4, hipMemcpyHostToDevice)) != hipSuccess
+        || (e = hipMemcpy(g_l2.d_vals, vals.data(), (size_t) slots * 8, hipMemcpyHostToDevice)) != hipSuccess) {
         (void) hipGetLastError();
         if (g_l2.d_keys) (void) hipFree(g_l2.d_keys);
         if (g_l2.d_vals) (void) hipFree(g_l2.d_vals);
         g_l2.d_keys = nullptr; g_l2.d_vals = nullptr;
-        return;
+        snprintf(g_l2_err, sizeof g_l2_err, "%llu corrections could not be brought onto the device (%s)",
+                 (unsigned long long) list.size(), hipGetErrorString(e));
+        return false;
     }
     g_l2.mask = slots - 1;
+    g_l2.ok = true;
+    return true;
 }
 
 /* ------------------------------------------------------------------ slab pool */
@@ -540,6 +614,7 @@ struct Staged {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ok = false;
     char err[200] = "";
+    int  ncu = 256;                /* CUs of the device the batch was staged for */
     /* launch in flight (fa_core_submit .. fa_core_finish) */
     std::vector<size_t>   batch;
     std::vector<DevFrame> hf;
@@ -601,7 +676,7 @@ struct Staged {
 /* of the G workgroups of a frame: the chain, T table workers, G - 1 - T verifiers */
 static int spec_workers(int G)
 {
-    const char *e = getenv("FIASCO_AMD_SPEC_T");           /* experiments */
+    const char *e = fa_knob("FIASCO_AMD_SPEC_T");           /* experiments */
     if (e && atoi(e) >= 0 && atoi(e) < G - 1) return atoi(e);
     return G >= 6 ? 2 : G >= 4 ? 1 : 0;
 }
@@ -632,9 +707,9 @@ static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only
 
 static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only)
 {
-    const char *e = getenv("FIASCO_AMD_SPEC");
+    const char *e = fa_knob("FIASCO_AMD_SPEC");
     if (e && atoi(e) <= 1) return 0;
-    if (getenv("FIASCO_AMD_TRACE") || getenv("FIASCO_AMD_NO_WIDE") || getenv("FIASCO_AMD_FORCE_TRI")) return 0;
+    if (fa_knob("FIASCO_AMD_TRACE") || fa_knob("FIASCO_AMD_NO_WIDE") || fa_knob("FIASCO_AMD_FORCE_TRI")) return 0;
     int occ = fc_occupancy_spec();
     if (occ < 1) occ = 1;
     if (!frames) return 0;
@@ -803,7 +878,7 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
     /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
-    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !getenv("FIASCO_AMD_NO_QUEUE");
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !fa_knob("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
@@ -875,8 +950,8 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     /* developer aid: FIASCO_AMD_POISON=<byte> fills the slab first -- the kernel must write every
      * cell before it reads it, whatever an earlier frame left there */
-    if (fs.base && getenv("FIASCO_AMD_POISON"))
-        (void) hipMemsetAsync(fs.base, atoi(getenv("FIASCO_AMD_POISON")), fs.L.total, S->stream);
+    if (fs.base && fa_knob("FIASCO_AMD_POISON"))
+        (void) hipMemsetAsync(fs.base, atoi(fa_knob("FIASCO_AMD_POISON")), fs.L.total, S->stream);
     if (!fs.base) {
         snprintf(job->errmsg, sizeof job->errmsg, "out of HBM: frame needs %.2f GiB", fs.L.total / 1073741824.0);
         return 0;
@@ -971,7 +1046,14 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                      "libfiasco_amd: no HIP device available (the hot path has no CPU fallback)");
         return S;
     }
-    log2_patch_build();                      /* once per process and device */
+    if (!log2_patch_build()) {               /* once per process and device */
+        /* frames coded without it could differ from the reference's: fail them, loudly */
+        for (unsigned i = 0; i < n; i++)
+            snprintf(jobs[i].errmsg, sizeof jobs[i].errmsg,
+                     "libfiasco_amd: no log2 correction table, streams could differ from the reference's "
+                     "(FIASCO_AMD_NO_LOG2_TABLE=1 encodes without it): %s", g_l2_err);
+        return S;                             /* S->ok stays false: nothing of this batch runs */
+    }
     int specG = 0;
     {
         int dev = 0, ncu = 0;
@@ -987,7 +1069,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
             if (needs_wide_variant(cp) || blocks + blocks * 3 / 8 + 64 + FC_SPEC_MAXG * FC_SPEC_TEMPS > 3072) narrow_only = false;
         }
         specG = spec_groups(n, ncu, n > 0 && jobs[0].image && (jobs[0].image->width > 2048 || jobs[0].image->height > 2048), narrow_only);
-        S->specG = specG;
+        S->specG = specG; S->ncu = ncu;
     }
     if (hipStreamCreate(&S->stream) != hipSuccess || hipEventCreate(&S->ev0) != hipSuccess
         || hipEventCreate(&S->ev1) != hipSuccess
@@ -1006,8 +1088,8 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         size_t guess = blocks + blocks * 3 / 8 + 64;
         /* tests / experiments: FIASCO_AMD_CAP_GUESS=<states> forces the first guess (a frame that
          * outgrows it is encoded again with 1.5 x the capacity, complete_wave) */
-        if (getenv("FIASCO_AMD_CAP_GUESS") && atoi(getenv("FIASCO_AMD_CAP_GUESS")) > 0)
-            guess = (size_t) atoi(getenv("FIASCO_AMD_CAP_GUESS"));
+        if (fa_knob("FIASCO_AMD_CAP_GUESS") && atoi(fa_knob("FIASCO_AMD_CAP_GUESS")) > 0)
+            guess = (size_t) atoi(fa_knob("FIASCO_AMD_CAP_GUESS"));
         if (guess > cp->limit_states) guess = cp->limit_states;
         FrameSlot fs;
         fs.job = (int) i;
@@ -1015,7 +1097,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
                 /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
-        const bool build1 = !specG && getenv("FIASCO_AMD_SPEC_BUILD1") != nullptr;
+        const bool build1 = !specG && fa_knob("FIASCO_AMD_SPEC_BUILD1") != nullptr;
         if ((specG || build1) && !fs.big) {
             /* the 256-thread build up to 3072 states, the 1024-thread one (4K; frames beyond the narrow
              * build's LDS pools) up to 12288 */
@@ -1023,7 +1105,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
             if (withids <= 12 * 1024 && withids <= align_up(cp->limit_states, 64)) { fs.spec = true; fs.P = (int) withids; }
         }
         /* tests: the triangular layout (chosen below for HBM-bound batches) for every default-geometry frame */
-        if (!fs.big && getenv("FIASCO_AMD_FORCE_TRI")) fs.tri = true;
+        if (!fs.big && fa_knob("FIASCO_AMD_FORCE_TRI")) fs.tri = true;
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
@@ -1041,7 +1123,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    if (!S->slots.empty() && !getenv("FIASCO_AMD_NO_TIGHT")) {
+    if (!S->slots.empty() && !fa_knob("FIASCO_AMD_NO_TIGHT")) {
         /* HBM-bound batches (4K: a slab is 3 GB, 97 % of it the Gram tables, quadratic in the state
          * capacity): when the slabs the chip could keep busy do not fit, the capacity guess drops
          * from 1.375 to 1.15 states per block of the largest block level -- a third more frames in
@@ -1070,7 +1152,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
              * states: 4K), where memory is what keeps CUs idle.  FIASCO_AMD_NO_TRI keeps the full tables. */
             for (size_t k = 0; k < S->slots.size(); k++) {
                 FrameSlot &fs = S->slots[k];
-                if (!fs.big && fs.P > 12 * 256 && !getenv("FIASCO_AMD_NO_TRI")) fs.tri = true;
+                if (!fs.big && fs.P > 12 * 256 && !fa_knob("FIASCO_AMD_NO_TRI")) fs.tri = true;
             }
             FrameSlot probe2 = S->slots[0];
             slot_layout(S, probe2);
@@ -1106,8 +1188,8 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (wide build for P > 3072: one per CU) */
                 S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only);
-                if (getenv("FIASCO_AMD_QUEUE_SLABS") && atoi(getenv("FIASCO_AMD_QUEUE_SLABS")) > 0)
-                    S->lender_cap = (size_t) atoi(getenv("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
+                if (fa_knob("FIASCO_AMD_QUEUE_SLABS") && atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS")) > 0)
+                    S->lender_cap = (size_t) atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
             } else if (elig && queue_layout(S, fs)) S->lenders++;
             continue;
         }
@@ -1362,7 +1444,7 @@ static bool launch_wave(Staged *S)
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        const bool few = batch.size() <= (size_t) cus && !getenv("FIASCO_AMD_NO_WIDE");
+        const bool few = batch.size() <= (size_t) cus && !fa_knob("FIASCO_AMD_NO_WIDE");
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
@@ -1372,9 +1454,9 @@ static bool launch_wave(Staged *S)
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
                     /* groups 5, 6: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
-                    const bool spec = fs.spec && (S->specG >= 2 || getenv("FIASCO_AMD_SPEC_BUILD1")) && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
+                    const bool spec = fs.spec && (S->specG >= 2 || fa_knob("FIASCO_AMD_SPEC_BUILD1")) && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
                     /* (FIASCO_AMD_SPEC_WIDE=0 / 1: experiments with the width of the workgroups) */
-                    const char *sw = getenv("FIASCO_AMD_SPEC_WIDE");
+                    const char *sw = fa_knob("FIASCO_AMD_SPEC_WIDE");
                     const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only || (sw && atoi(sw) == 1));
                     if ((spec ? (spec_wide ? 6 : 5) : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
@@ -1390,7 +1472,7 @@ static bool launch_wave(Staged *S)
     std::vector<DevFrame> &hf = S->hf;
     hf.resize(batch.size());
     S->d_trace = nullptr;
-    const char *trace_path = getenv("FIASCO_AMD_TRACE");
+    const char *trace_path = fa_knob("FIASCO_AMD_TRACE");
     const int trace_cap = 400000;
     for (size_t b = 0; b < batch.size(); b++) hf[b] = S->slots[batch[b]].F;
     {   /* where every frame packs its finished automaton */
@@ -1528,7 +1610,7 @@ static bool launch_wave(Staged *S)
                 h.tab_stride = (unsigned) max_tab;
                 /* 120 us: about what the chain needs to build the tables itself (tests: FIASCO_AMD_SPEC_TABWAIT=0
                  * makes it take the worker's tables only when they are there already) */
-                h.tab_wait = getenv("FIASCO_AMD_SPEC_TABWAIT") ? (unsigned) atoi(getenv("FIASCO_AMD_SPEC_TABWAIT")) : 12000u;
+                h.tab_wait = fa_knob("FIASCO_AMD_SPEC_TABWAIT") ? (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_TABWAIT")) : 12000u;
                 h.off_blocks = off_blocks; h.off_tabs = off_tabs;
                 fail = hipMemcpy(S->d_spec + span * i, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess;
                 if (!fail && !lists[i].empty())
@@ -1547,7 +1629,7 @@ static bool launch_wave(Staged *S)
                                   unsigned long long, hipStream_t);
         /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
         unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
-        if (getenv("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(getenv("FIASCO_AMD_QUEUE_WAIT_MS"));
+        if (fa_knob("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_QUEUE_WAIT_MS"));
         static const launch_fn launch[5] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri };
         size_t first = 0;
         for (int k = 0; k < 2 && !fail; k++) {
@@ -1619,7 +1701,7 @@ static void complete_wave(Staged *S)
             }
         else (void) hipGetLastError();
     }
-    const char *trace_path = getenv("FIASCO_AMD_TRACE");
+    const char *trace_path = fa_knob("FIASCO_AMD_TRACE");
     if (S->d_trace && !fail && trace_path) {
         std::vector<FcTrace> tr((size_t) hf[0].trace_n);
         if (hipMemcpy(tr.data(), S->d_trace, sizeof(FcTrace) * tr.size(), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1688,11 +1770,19 @@ static void complete_wave(Staged *S)
         fs.F.trace = (FcTrace *) tr_keep; fs.F.trace_cap = 0;
         if (fs.ext_pix) fs.F.pix16 = fs.ext_pix;
         size_t cap = align_up(job->cp.limit_states, 64);
-        if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap)) {
+        /* (a frame that shares its slab with verifiers has less than fs.P for itself -- their private
+         * state ids lie at the top of the capacity --: at the state limit it is encoded once more by one
+         * workgroup with all of it, like the reference would, before "Maximum number of states" is said) */
+        if (st == FC_ERR_CAPACITY && ((size_t) fs.P < cap || (size_t) fs.PA < cap || fs.spec)) {
             /* capacity guess too small: bigger slab, same inputs, encode again */
             g_stats.reencodes += 1;
             size_t np = align_up((size_t) fs.P + (size_t) fs.P / 2, 64);
             size_t npa = align_up((size_t) fs.PA + (size_t) fs.PA / 2, 64);
+            if ((size_t) fs.P >= cap || np >= cap) fs.spec = false;
+            /* a frame of a launch with more workgroups than CUs that outgrows the 256-thread build would come
+             * back in the 1024-thread speculating build, one workgroup per CU: its verifiers might not be
+             * resident (the chain's waits are bounded, but slow) -- one workgroup for such a frame */
+            if (np > 3072 && S->specG > 1 && (size_t) S->specG * S->n > (size_t) S->ncu) fs.spec = false;
             if (fs.base) slab_release(fs.base, fs.bytes);
             /* a borrower gets a slab of its own; its pixel planes stay where they are (the queue's
              * pixel buffer or an upload buffer): the host copy may belong to the next pass by now */

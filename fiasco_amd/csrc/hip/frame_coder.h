@@ -183,9 +183,9 @@ typedef struct DevFrame {
  *
  *  Per frame, in HBM: this control block, then FC_SPEC_W checkpoint slots of sizeof(Sh) bytes (the
  *  complete LDS state of the chain at the entry of a block: input of the verifier, and what the
- *  chain returns to after a wrong guess), then FC_SPEC_W result slots of the same size (a verifier
- *  that finds the subdivision of its block to win leaves its own LDS state there: the chain takes it
- *  over instead of searching the block again).
+ *  chain returns to after a wrong guess), then one result slot of the same size PER VERIFIER (index
+ *  role - T - 1; a verifier that finds the subdivision of its block to win leaves its own LDS state
+ *  there: the chain takes it over instead of searching the block again).
  *
  *  Table workers.  A third of what is left to the chain is init_range: the <sub-block, state> tables
  *  of the next block for every state of the dictionary (codec/ip.c:72-154, codec/subdivide.c:612-644).
@@ -210,7 +210,9 @@ typedef struct FcSpecCtl {
     unsigned busy;              /* verifiers inside a block search (the chain waits for 0 before the chroma bands re-use their state ids) */
     unsigned slot_bytes;        /* size of a checkpoint slot */
     unsigned slot_seq[FC_SPEC_W];   /* seq + 1 once the checkpoint of block `seq` is complete, 0 while written */
-    unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 8 | state ids the search used << 2 | code: 1 the combination wins, 2 anything else */
+    unsigned verdict[FC_SPEC_W];    /* (seq + 1) << 11 | verifier (role - T - 1) << 8 | state ids the search used << 2 | code:
+                                     * 1 the combination wins, 2 anything else, 3 the subdivision wins and the verifier's
+                                     * finished search waits in ITS result slot (frame_coder.hip, end of a verifier's task; spec_poll) */
     /* statistics (chain) */
     unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
     unsigned long long n_tab_used, n_tab_missed;      /* blocks whose tables came from a worker / were not there in time */

@@ -2054,6 +2054,12 @@ __device__ int band_advance(DevFrame &__restrict__ F, Sh &__restrict__ sh)
 }
 
 #if FC_SPEC
+/* The chain raises `epoch` and then reads `busy`; a verifier counts itself into `busy` and then reads
+ * `epoch`: a store followed by a load of ANOTHER word on each side (Dekker).  Release / acquire alone
+ * order neither pair; a sequentially consistent fence between the two accesses does -- at least one of
+ * the two sides then sees the other's write, so either the verifier drops the block or the chain waits
+ * for it.  (Before round 4 this held only because both words share a cache line of FcSpecCtl.) */
+#define SPEC_DEKKER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent")
 #define SPEC_TIMEOUT_TICKS 20000000ull      /* 0.2 s of the 100 MHz wall clock: then the chain does the block itself */
 /* Chain, lane 0: consume the verdicts that have arrived, in block order.  `drain`: wait for all of
  * them (end of the frame); otherwise wait only while every checkpoint slot is taken.  Returns 0, or 1 +
@@ -2124,6 +2130,7 @@ __device__ __noinline__ void spec_luminance_done(Sh &sh)
     FcSpecCtl *c = sh.sl.ctl;
     sh.sl.epoch++;
     __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    SPEC_DEKKER_FENCE();
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         if (wall_clock64() - t0 > 100000000ull) { sh.failed = FC_ERR_INTERNAL; break; }     /* 1 s */
@@ -3227,6 +3234,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             sh.op = valid ? OP_NOP : OP_DONE;
             if (valid) {
                 atomicAdd(&c->busy, 1u);
+                SPEC_DEKKER_FENCE();
                 /* (the chain may have raised the epoch between the check above and this count: once more) */
                 if (__hip_atomic_load(&c->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != task_epoch) {
                     atomicSub(&c->busy, 1u); valid = false; sh.sl.abort = 1; sh.op = OP_DONE;
@@ -3332,6 +3340,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                     __hip_atomic_store(&c->adopting, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     sh.sl.epoch++;
                     __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    SPEC_DEKKER_FENCE();
                     while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);
                     sh.sl.n_adopted++;
                     sh.gap_lo = sh.gap_hi = sh.gap_shift = 0; sh.deadmask = 0;
@@ -3408,6 +3417,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                     __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     sh.sl.epoch++;                        /* ... and its verifier should drop it */
                     __hip_atomic_store(&c->epoch, sh.sl.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    SPEC_DEKKER_FENCE();
                     /* ... before the search here appends a state: rows from this state count on, read by a
                      * search that has not looked at the epoch yet, would change under it */
                     while (__hip_atomic_load(&c->busy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);

@@ -414,7 +414,7 @@ typedef struct { fiasco_amd_batch_t *b; unsigned char **outv; size_t *out_len; u
  * writer (diff the dumps of two cores to find what the per-call traces cannot show) */
 static void dump_wfa(const fa_wfa *w)
 {
-    const char *path = getenv("FIASCO_DUMP_WFA");
+    const char *path = fa_knob("FIASCO_DUMP_WFA");
     FILE *f;
     unsigned s, l, e;
     if (!path || !(f = fopen(path, "a"))) return;

@@ -44,6 +44,9 @@ enum { FA_GRAY = 0, FA_Y = 0, FA_CB = 1, FA_CR = 2 };
 
 /* ---------------- error / messages (reference lib/error.c) ---------------- */
 void fa_set_error(const char *fmt, ...);
+/* getenv() for developer / test switches: null unless FIASCO_AMD_DEBUG is set (core_hip.cpp; the oracle's
+ * core has its own) */
+const char *fa_knob(const char *name);
 void fa_warning(const char *fmt, ...);
 void fa_message(const char *fmt, ...);
 void fa_debug(const char *fmt, ...);

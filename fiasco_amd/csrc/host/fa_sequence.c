@@ -306,7 +306,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
         }
         t_dec += seq_now() - t0;
     }
-    if (getenv("FIASCO_AMD_SEQ_TIMING"))
+    if (fa_knob("FIASCO_AMD_SEQ_TIMING"))
         fprintf(stderr, "fa_seq_search: %u GOPs, %u steps: prepare %.2f s, core %.2f s, decode %.2f s\n",
                 nrun, maxlen, t_prep, t_core, t_dec);
     for (r = 0; r < nrun; r++) {

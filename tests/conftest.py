@@ -10,6 +10,7 @@ Only tests may touch oracle/ (the product never does).
 import hashlib
 import json
 import os
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import subprocess
 import sys
 

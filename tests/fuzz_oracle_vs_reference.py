@@ -13,6 +13,7 @@ tests/fuzz_parity.py.
 usage: fuzz_oracle_vs_reference.py [cases] [seed0] [workers]
 """
 import os
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import subprocess
 import sys
 import tempfile

@@ -3,6 +3,7 @@ pricing) and through one wide workgroup per frame / several workgroups per frame
 must be the same.  usage: gpu_cross_build.py W H n [reps]"""
 import hashlib
 import os
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

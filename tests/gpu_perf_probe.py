@@ -2,6 +2,7 @@
 usage: gpu_perf_probe.py W H n_frames n_distinct [repeats]"""
 import hashlib
 import os
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import sys
 import time
 

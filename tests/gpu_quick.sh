@@ -22,7 +22,7 @@ for f in $names; do
   s0=$(date +%s%N)
   FIASCO_ORACLE_TRACE=gpurun_out/q/$f.or.trace oracle/cfiasco_oracle --progress-meter 0 ${QUICK_ARGS:-} -o gpurun_out/q/$f.or.fco gpurun_out/q/$f.pnm
   s1=$(date +%s%N)
-  FIASCO_AMD_TRACE=gpurun_out/q/$f.gpu.trace timeout 120 fiasco_amd/bin/cfiasco --progress-meter 0 ${QUICK_ARGS:-} -o gpurun_out/q/$f.gpu.fco gpurun_out/q/$f.pnm
+  FIASCO_AMD_DEBUG=1 FIASCO_AMD_TRACE=gpurun_out/q/$f.gpu.trace timeout 120 fiasco_amd/bin/cfiasco --progress-meter 0 ${QUICK_ARGS:-} -o gpurun_out/q/$f.gpu.fco gpurun_out/q/$f.pnm
   s2=$(date +%s%N)
   echo "$f: oracle $(( (s1-s0)/1000000 )) ms, device $(( (s2-s1)/1000000 )) ms (process start + hip init included)"
   echo "$f: oracle $(stat -c %s gpurun_out/q/$f.or.fco) $(md5sum < gpurun_out/q/$f.or.fco | cut -c1-12)  device $(stat -c %s gpurun_out/q/$f.gpu.fco) $(md5sum < gpurun_out/q/$f.gpu.fco | cut -c1-12)"

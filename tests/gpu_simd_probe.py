@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import synth, fiasco_amd
 lib = fiasco_amd.library(); lib.set_verbosity(0)

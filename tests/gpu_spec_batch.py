@@ -1,6 +1,7 @@
 """Developer helper: frames/s of small batches with and without block-level speculation.
 usage: gpu_spec_batch.py W H n [mode ...]    mode: 0 | default | G | G:T"""
 import os, sys, time, hashlib
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth, fiasco_amd

@@ -2,6 +2,7 @@
 large frames (more than 3072 states; limits extension) -- device against device, the one-workgroup path is
 pinned against the reference elsewhere.  usage: gpu_spec_fuzz_wide.py [cases] [seed]"""
 import os, sys, time
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@ one-workgroup-per-frame launch -- same bytes?  how much faster?
 usage: gpu_spec_probe.py [W H n_frames [G ...]]      (G = 0: speculation off)"""
 import hashlib
 import os
+os.environ.setdefault("FIASCO_AMD_DEBUG", "1")     # the library honours its developer switches only with this
 import sys
 import time
 

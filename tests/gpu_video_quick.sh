@@ -15,7 +15,7 @@ for f in range(n):
 PY
 files=$(ls gpurun_out/q/v?.pnm | head -$n)
 FIASCO_ORACLE_TRACE=gpurun_out/q/v.or.trace oracle/cfiasco_oracle --progress-meter 0 "$@" -o gpurun_out/q/v.or.fco $files
-FIASCO_AMD_TRACE=gpurun_out/q/v.gpu.trace timeout 300 fiasco_amd/bin/cfiasco --progress-meter 0 "$@" -o gpurun_out/q/v.gpu.fco $files
+FIASCO_AMD_DEBUG=1 FIASCO_AMD_TRACE=gpurun_out/q/v.gpu.trace timeout 300 fiasco_amd/bin/cfiasco --progress-meter 0 "$@" -o gpurun_out/q/v.gpu.fco $files
 echo "oracle $(stat -c %s gpurun_out/q/v.or.fco) $(md5sum < gpurun_out/q/v.or.fco | cut -c1-12)  device $(stat -c %s gpurun_out/q/v.gpu.fco) $(md5sum < gpurun_out/q/v.gpu.fco | cut -c1-12)"
 python3 tests/trace_diff.py gpurun_out/q/v.or.trace gpurun_out/q/v.gpu.trace
 rm -f gpurun_out/q/v?.pnm

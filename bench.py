@@ -166,6 +166,55 @@ def small_launches(lib, opt, uniq, w, h):
     return res
 
 
+def k4_pass(lib, nframes, rank):
+    """BASELINE config 4's workload on ONE GPU, driver-timed: `nframes` independent 3840x2160 grayscale
+    frames in one launch (declared limits extension, SURVEY 8c: the stock reference cannot encode 4K),
+    inputs resident in HBM, one pass (kernel + automaton download + .fco writer).  Frame 0 is the survey
+    image, whose stream must be the patched reference's (md5 b1216151..., SURVEY App. C and
+    tests/golden/MANIFEST_BIG.json)."""
+    import fiasco_amd
+    w, h = 3840, 2160
+    seeds = [1234 if (rank == 0 and i == 0) else 200000 + i for i in range(nframes)]
+    tg = time.perf_counter()
+    frames = make_frames(w, h, seeds)
+    t_gen = time.perf_counter() - tg
+    lib.L.fiasco_amd_release_memory()          # the slabs of the 1080p batch
+    lib.set_limits(30000, 26)
+    o = lib.cli_options()
+    try:
+        ts = time.perf_counter()
+        b = fiasco_amd.Batch(lib, frames, 20.0, o)
+        t_stage = time.perf_counter() - ts
+        import torch
+        torch.cuda.synchronize()
+        lib.reset_stats()
+        t0 = time.perf_counter()
+        out = b.encode()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = lib.get_stats()
+        b.free()
+    finally:
+        o.delete()
+        lib.set_limits(6000, 22)
+        lib.L.fiasco_amd_release_memory()
+    ok = out is not None and all(x is not None for x in out)
+    alg = float(st.bytes_mp + st.bytes_img + st.bytes_gram)
+    ks = st.kernel_ms / 1e3
+    md5 = hashlib.md5(out[0]).hexdigest() if ok else None
+    return {"frames": nframes, "all_encoded": ok, "frames_per_s": nframes / dt if ok else None, "seconds": dt,
+            "kernel_only_frames_per_s": st.frames / ks if ks else None, "launches": int(st.launches),
+            "reencoded_frames": int(st.reencodes), "frames_by_kernel_build": list(st.frames_by_build),
+            "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9 if ks else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": None,
+                         "kernel": "fiasco_frame_kernel_wide_tri", "avg_launch_ms": st.kernel_ms / max(st.launches, 1),
+                         "algorithmic_bytes_per_launch": alg / max(st.launches, 1)},
+            "parity": ("stream md5 of survey frame == patched reference (%s)" % md5[:12])
+                      if md5 == REF_MD5_SEED1234[(w, h)] else "MISMATCH: %s" % md5,
+            "stage_seconds": t_stage, "generate_seconds": t_gen,
+            "limits": "MAXSTATES 30000, MAXLEVEL 26 (declared extension, SURVEY 8c)"}
+
+
 # ---- synthetic frames: one seed per frame (SURVEY Appendix C generator, tests/synth.py) ----
 
 _BASE = {}
@@ -219,6 +268,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie-loop", action="store_true", help="skip the PCIe-inclusive timed loop")
     ap.add_argument("--no-small-launches", action="store_true", help="skip the single-frame / 16-frame timings")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank encodes --frames-per-gpu frames (default); strong: --frames-per-gpu is the "
+                         "TOTAL of the job, dealt round robin to the ranks (BASELINE config 4: --scaling strong "
+                         "--width 3840 --height 2160 --frames-per-gpu 64 on 1/2/4/8 GPUs)")
+    ap.add_argument("--k4-frames", type=int, default=256,
+                    help="frames of the extra 3840x2160 pass (BASELINE config 4 on one GPU; 0 = skip)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -240,9 +295,15 @@ def main():
         local = 0
 
     F = a.frames_per_gpu
+    total_job = world * F
+    if a.scaling == "strong":
+        # the job is F frames in all; rank r takes the frames r, r + W, ... (sharding.shard_indices)
+        total_job = F
+        F = len(range(rank, total_job, world))
+        assert F > 0, "--scaling strong: fewer frames than ranks"
     ndist = a.distinct if a.distinct > 0 else F
     # frame 0 of rank 0 is the survey image (seed 1234) whose reference stream md5 is known
-    seeds = [1234 if (rank == 0 and i == 0) else 100000 + rank * F + i for i in range(ndist)]
+    seeds = [1234 if (rank == 0 and i == 0) else 100000 + rank * a.frames_per_gpu + i for i in range(ndist)]
     tg = time.perf_counter()
     uniq = make_frames(a.width, a.height, seeds) if not dry else [b"P5\n32 32\n255\n" + bytes(1024)] * ndist
     t_gen = time.perf_counter() - tg
@@ -320,6 +381,10 @@ def main():
         dt = time.perf_counter() - t0
         st = lib.get_stats()
         root = batch.stats(0)          # coder-side error of the survey frame
+        try:                           # ... and its decoded PSNR (dfiasco -s 0 + pnmpsnr)
+            decoded_psnr = batch.decode_psnr(0)[0][0] if rank == 0 else None
+        except Exception:
+            decoded_psnr = None
         assert out is not None and all(o is not None for o in out), lib.error_message()
         # ---- loop B: the frames of every pass cross PCIe inside the timed region ----
         if not a.no_pcie_loop:
@@ -347,7 +412,9 @@ def main():
             assert all(out2[j] == out[(j + k) % F] for j in range(0, F, max(1, F // 64))), \
                 "pipelined pass did not encode the uploaded frames"
         batch.free()
-        small = None
+        small = k4 = None
+        if rank == 0 and world == 1 and a.k4_frames > 0 and (a.width, a.height) == (1920, 1080):
+            k4 = k4_pass(lib, a.k4_frames, rank)
         if rank == 0 and world == 1 and not a.no_small_launches and (a.width, a.height) == (1920, 1080):
             small = small_launches(lib, opt, uniq, a.width, a.height)
 
@@ -362,7 +429,7 @@ def main():
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         # trivial gather of the per-rank streams over RCCL (outside the timed region)
         # global item r + i*W is frame i of rank r (round-robin, sharding.shard_indices)
-        ng = min(F, 64)                      # a sample of every rank's streams
+        ng = min(total_job // world if a.scaling == "strong" else F, 64)      # a sample of every rank's streams (same count on all)
         keys = shard_indices(world * ng, rank, world)
         local_streams = {k: out[i] for i, k in enumerate(keys)}
         alls = gather_streams(local_streams, world * ng, device=cdev)
@@ -374,7 +441,7 @@ def main():
         md5_ref = REF_MD5_SEED1234.get((a.width, a.height))
         if md5_ref and not dry:
             assert hashlib.md5(out[0]).hexdigest() == md5_ref, "parity lost: stream differs from the reference"
-        total_frames = world * F * a.steps
+        total_frames = total_job * a.steps
         value = total_frames / dt if not dry else None
         per_launch_bytes = alg_bytes / max(launches, 1)
         if not dry and alg_override is not None and world == 1:
@@ -384,13 +451,15 @@ def main():
         res = {
             "metric": "grayscale frames/sec encoded",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batch of %d independent %dx%d grayscale PGM frames per GPU (%d distinct "
                                    "seeds per GPU), cfiasco defaults (-q 20, block levels 6..10, 3 elements, "
                                    "small.fco basis, rle/adaptive models), bit-identical .fco streams"
-                                   % (F, a.width, a.height, ndist),
-                       "frames_per_gpu": F, "distinct_frames_per_gpu": ndist,
+                                   % (a.frames_per_gpu if a.scaling == "weak" else F, a.width, a.height, ndist)
+                                   + ("" if a.scaling == "weak" else "; strong scaling: %d frames in all, dealt round robin "
+                                                                      "to %d ranks" % (total_job, world)),
+                       "frames_per_gpu": F, "distinct_frames_per_gpu": ndist, "frames_total_per_step": total_job,
                        "parallelism": "frames x%d" % world,
                        "kernel_only_frames_per_s": nframes / (kernel_ms / 1e3) * world if kernel_ms else None,
                        # raw PNM in host memory -> parse -> pinned -> HBM inside the timed region,
@@ -401,6 +470,18 @@ def main():
                        "stage_seconds_first_batch": t_stage, "generate_seconds": t_gen,
                        "parity": ("stream md5 of survey frame == reference (%s)" % md5_ref[:12]) if md5_ref else None,
                        "estimated_psnr_db": root["psnr_db"] if root else None,
+                       # decoded like `dfiasco -s 0`, compared like bin/pnmpsnr.c (reference tools on the
+                       # reference's stream of the survey frame: 34.02 dB, tests/golden/MANIFEST.json)
+                       "decoded_psnr_db": decoded_psnr if not dry else None,
+                       # what `value` times and what it does not: the reference's own timer (codec/coder.c:709,884)
+                       # also covers reading the PNM file and writing the .fco file
+                       "value_covers": "device search + automaton download + host .fco entropy writer into memory, "
+                                       "inputs resident in HBM; NOT PNM file read / parse / upload (see "
+                                       "pcie_inclusive_frames_per_s) and NOT writing the .fco files to disk",
+                       # BASELINE config 4's workload on this GPU: 256 x 3840x2160 in one launch (north-star
+                       # target: >= 50 frames/s on one GPU)
+                       "k4_frames_per_s": (k4 or {}).get("frames_per_s") if not dry else None,
+                       "k4": k4 if not dry else None,
                        # launches that leave the chip empty: several workgroups per frame (speculation)
                        "small_launches": small if not dry else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -36,8 +36,8 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats",
-    "fiasco_amd_release_memory", "fiasco_amd_batch_upload",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr",
+    "fiasco_amd_release_memory", "fiasco_amd_batch_upload", "fiasco_amd_set_devices", "fiasco_amd_device_count",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
     "fiasco_amd_seq_open", "fiasco_amd_seq_free", "fiasco_amd_seq_gops", "fiasco_amd_seq_frames",
@@ -141,6 +141,16 @@ class Library:
         a, b = ctypes.c_uint(), ctypes.c_uint()
         self.L.fiasco_amd_get_limits(ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
+
+    def set_devices(self, ids):
+        """fiasco_amd_set_devices: the devices the batch entries spread their frames over ([] = automatic)."""
+        arr = (ctypes.c_int * max(len(ids), 1))(*ids)
+        self.L.fiasco_amd_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        if not self.L.fiasco_amd_set_devices(arr, len(ids)):
+            raise FiascoError(self.error_message())
+
+    def device_count(self):
+        return self.L.fiasco_amd_device_count()
 
     def set_device(self, device):
         self.L.fiasco_amd_set_device.argtypes = [ctypes.c_int]
@@ -288,6 +298,17 @@ class Batch:
         mse = err.value / w.value / h.value
         return {"costs": costs.value, "err": err.value, "width": w.value, "height": h.value,
                 "psnr_db": 10.0 * math.log10(255.0 * 255.0 / mse) if mse > 0 else float("inf")}
+
+    def decode_psnr(self, i):
+        """fiasco_amd_batch_decode_psnr: decoded PSNR in dB per band of frame i (what `dfiasco -s 0` +
+        `pnmpsnr` print for a gray frame), and the mean squared errors."""
+        f = self.lib.L.fiasco_amd_batch_decode_psnr
+        f.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        f.restype = ctypes.c_int
+        ps, ms = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
+        if not f(self.handle, i, ps, ms):
+            raise FiascoError(self.lib.error_message())
+        return list(ps), list(ms)
 
     def free(self):
         if self.handle:

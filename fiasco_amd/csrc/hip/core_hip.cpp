@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include <utility>
 #include <vector>
 #include "fa_host.h"
@@ -27,12 +28,37 @@
  * are honoured only when FIASCO_AMD_DEBUG is set to something other than 0: a drop-in library must not
  * change its behaviour because of a stray variable in a user's environment.  What a user may set without
  * it: FIASCO_AMD_CACHE (cache directory), FIASCO_AMD_NO_LOG2_TABLE (encode without the log2 correction
- * table), FIASCO_AMD_DEVICES (devices of the multi-device batch entries, fa_multi.cpp). */
+ * table), FIASCO_AMD_DEVICES (devices the batch entries spread their frames over, end of this file). */
 extern "C" const char *fa_knob(const char *name)
 {
     const char *d = getenv("FIASCO_AMD_DEBUG");
     return d && *d && strcmp(d, "0") != 0 ? getenv(name) : nullptr;
 }
+
+
+/* ------------------------------------------------------------------ per-device state
+ *
+ * Everything the launcher keeps between calls belongs to ONE device: the pool of slabs, the log2
+ * correction table, the counters.  A process that encodes on one device (the default on a 1-GPU box, a
+ * rank of the multi-process harness after fiasco_amd_set_device()) uses g_state0 from whatever thread
+ * calls in.  The multi-device entries at the end of this file give every further device a DevState of its
+ * own and run its share of a batch on a host thread whose t_dev points there. */
+struct PoolEntry { char *base; size_t bytes; };
+struct Log2Patch { unsigned *d_keys = nullptr; double *d_vals = nullptr; unsigned mask = 0; int device = -1;
+                   unsigned long long entries = 0; bool tried = false, ok = false; };
+struct DevState {
+    fiasco_amd_stats stats;
+    std::vector<PoolEntry> free;
+    Log2Patch l2;
+    char l2_err[200];
+    DevState() { memset(&stats, 0, sizeof stats); l2_err[0] = 0; }
+};
+static DevState g_state0;
+static thread_local DevState *t_dev = &g_state0;
+#define g_stats  (t_dev->stats)
+#define g_free   (t_dev->free)
+#define g_l2     (t_dev->l2)
+#define g_l2_err (t_dev->l2_err)
 
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
@@ -90,10 +116,7 @@ static bool needs_wide_variant(const fa_cparams *cp)
            || depths * 4 * ((2 * cp->limit_level + 3) / 4) > FC_SNAPTM_NARROW;
 }
 
-static fiasco_amd_stats g_stats;
-
-extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out) { *out = g_stats; }
-extern "C" void fiasco_amd_reset_stats(void) { memset(&g_stats, 0, sizeof g_stats); }
+/* (fiasco_amd_get_stats / _reset_stats: with the multi-device entries, end of file) */
 static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ);
 extern "C" int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int narrow_only, int occupancy)
 {
@@ -118,19 +141,7 @@ static size_t frames_per_cu(bool big, bool wide)
     return (size_t) cache[i];
 }
 
-/* one process per GPU: bind this process's coder to a device of the node */
 extern "C" void fiasco_amd_release_memory(void);
-extern "C" int fiasco_amd_set_device(int device)
-{
-    int cur = -1;
-    /* the slab pool holds memory of the device it was allocated on: never carry it over */
-    if (hipGetDevice(&cur) == hipSuccess && cur != device) fiasco_amd_release_memory();
-    if (hipSetDevice(device) != hipSuccess) {
-        fa_set_error("libfiasco_amd: cannot select HIP device %d", device);
-        return 0;
-    }
-    return 1;
-}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -188,9 +199,6 @@ static void *l2_thread(void *arg)
 }
 
 /* the table of host log2 values the kernels use (DevFrame.l2_*), per process */
-struct Log2Patch { unsigned *d_keys = nullptr; double *d_vals = nullptr; unsigned mask = 0; int device = -1;
-                   unsigned long long entries = 0; bool tried = false, ok = false; };
-static Log2Patch g_l2;
 static unsigned long long g_l2_max_ulp;      /* largest distance seen by the last comparisons, in ulps */
 extern "C" unsigned long long fiasco_amd_selftest_log2_max_ulp(void) { return g_l2_max_ulp; }
 
@@ -261,7 +269,6 @@ extern "C" int fiasco_amd_selftest_log2(unsigned exp_lo, unsigned exp_hi, unsign
 }
 
 static bool log2_patch_build(void);
-static char g_l2_err[200];
 
 /* the same comparison THROUGH the table the frame kernel uses: n_double must come out 0 */
 extern "C" int fiasco_amd_selftest_log2_patched(unsigned exp_lo, unsigned exp_hi, unsigned long long *n_checked,
@@ -418,8 +425,6 @@ static bool log2_patch_build(void)
 
 /* ------------------------------------------------------------------ slab pool */
 
-struct PoolEntry { char *base; size_t bytes; };
-static std::vector<PoolEntry> g_free;
 
 static char *slab_acquire(size_t bytes, size_t *got)
 {
@@ -455,12 +460,6 @@ static char *slab_acquire(size_t bytes, size_t *got)
 static void slab_release(char *p, size_t bytes)
 {
     if (p) g_free.push_back(PoolEntry{p, bytes});
-}
-
-extern "C" void fiasco_amd_release_memory(void)
-{
-    for (size_t i = 0; i < g_free.size(); i++) (void) hipFree(g_free[i].base);
-    g_free.clear();
 }
 
 /* ------------------------------------------------------------------ layout */
@@ -1004,7 +1003,7 @@ static int stage_slot(Staged *S, FrameSlot &fs)
     return 1;
 }
 
-extern "C" void fa_core_unstage(void *h)
+static void core1_unstage(void *h)
 {
     Staged *S = (Staged *) h;
     if (!S) return;
@@ -1034,7 +1033,7 @@ extern "C" void fa_core_unstage(void *h)
     delete S;
 }
 
-extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
+static void *core1_stage(unsigned n, fa_job *jobs)
 {
     Staged *S = new Staged;
     int ndev = 0;
@@ -1209,7 +1208,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
 
 /* ---- replacement inputs for a staged batch (a stream of batches) ---- */
 
-extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
+static int16_t *core1_upload_buffer(void *h, size_t bytes)
 {
     Staged *S = (Staged *) h;
     if (!S || !S->ok || !bytes) return nullptr;
@@ -1227,7 +1226,7 @@ extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
     return (int16_t *) S->up_host;
 }
 
-extern "C" int fa_core_upload_commit(void *h)
+static int core1_upload_commit(void *h)
 {
     Staged *S = (Staged *) h;
     if (!S || !S->ok || !S->up_host) return 0;
@@ -1831,7 +1830,7 @@ static void flush_unpack(Staged *S)
 }
 
 /* start encoding every staged frame; returns immediately (the kernel runs) */
-extern "C" int fa_core_submit(void *h)
+static int core1_submit(void *h)
 {
     Staged *S = (Staged *) h;
     if (!S || !S->ok) return 0;
@@ -1860,11 +1859,11 @@ extern "C" int fa_core_submit(void *h)
 /* wait for the submitted launch and bring every frame to completion (re-encodes with larger
  * slabs, later waves of a batch that did not fit into HBM at once).  After it returns the
  * jobs' automata are in host memory and the device is free for the next submit. */
-extern "C" int fa_core_finish2(void *h, int resubmit)
+static int core1_finish2(void *h, int resubmit)
 {
     Staged *S = (Staged *) h;
     if (!S || !S->ok) return 0;
-    if (!S->inflight) { fa_core_submit(h); }
+    if (!S->inflight) { core1_submit(h); }
     for (size_t k = 0; k < S->slots.size(); k++) S->jobs[S->slots[k].job].status = 0;
     for (;;) {
         if (S->inflight) { complete_wave(S); S->inflight = false; if (S->broken) break; }
@@ -1900,7 +1899,7 @@ extern "C" int fa_core_finish2(void *h, int resubmit)
         /* next pass on the device first, then the host-side unpacking of this one */
         std::vector<std::pair<size_t, size_t>> keep;
         keep.swap(S->to_unpack);
-        fa_core_submit(h);                         /* resets S->good */
+        core1_submit(h);                           /* resets S->good */
         S->to_unpack.swap(keep);
         int g = S->good;
         S->good = good_before;
@@ -1913,12 +1912,250 @@ extern "C" int fa_core_finish2(void *h, int resubmit)
     return S->good;
 }
 
+
+/* ------------------------------------------------------------------ several devices in one process
+ *
+ * Frames (separate fiasco_coder() calls, frames of a gray all-intra stream, the groups of pictures a
+ * sequence is coded in) are independent units (tiles are not: codec/tiling.c is dead code in
+ * this reference).  The seam fa_core_*() therefore spreads the jobs of a batch round robin over the
+ * devices of the process -- job i goes to device i mod D -- and runs every share on a host thread of its
+ * own with its own stream, slab pool and log2 table (DevState); results come back in job order.  No
+ * collective is involved: what crosses between devices is nothing, what comes back per frame is its
+ * automaton (kilobytes) over PCIe as before.  (The reference call site this serves: video_coder()'s
+ * frame loop, codec/coder.c:490-668.)
+ *
+ * Which devices: FIASCO_AMD_DEVICES="0,1,4" if set (an id may repeat -- two shares on one GPU: the test of
+ * this path on a 1-GPU box); else, once fiasco_amd_set_device(d) has been called -- one process per GPU,
+ * the multi-process harness -- just d; else every visible device.  With one device nothing below
+ * starts a thread or touches the current device: the calls run where they always ran. */
+static std::vector<int> g_devices;              /* empty = not resolved yet */
+static int  g_device_explicit = -1;             /* fiasco_amd_set_device() */
+static std::vector<DevState *> g_dev_state;     /* [k] for share k (k >= 1; share 0 uses g_state0) */
+static pthread_mutex_t g_dev_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void resolve_devices(void)
+{
+    pthread_mutex_lock(&g_dev_lock);
+    if (g_devices.empty()) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) { (void) hipGetLastError(); ndev = 0; }
+        const char *e = getenv("FIASCO_AMD_DEVICES");
+        if (e && *e) {
+            for (const char *q = e; *q; ) {
+                char *end;
+                long v = strtol(q, &end, 10);
+                if (end == q) break;
+                if (v >= 0 && v < ndev) g_devices.push_back((int) v);
+                q = *end ? end + 1 : end;
+            }
+        } else if (g_device_explicit >= 0) g_devices.push_back(g_device_explicit);
+        else for (int d = 0; d < ndev; d++) g_devices.push_back(d);
+        if (g_devices.empty()) g_devices.push_back(-1);      /* -1: whatever the current device is (or none) */
+        while (g_dev_state.size() < g_devices.size()) g_dev_state.push_back(g_dev_state.empty() ? &g_state0 : new DevState);
+    }
+    pthread_mutex_unlock(&g_dev_lock);
+}
+
+extern "C" int fiasco_amd_device_count(void)
+{
+    resolve_devices();
+    return (int) g_devices.size();
+}
+
+/* the devices of this process, chosen by the caller: n ids (an id may repeat), or n = 0 for the rule above */
+extern "C" int fiasco_amd_set_devices(const int *ids, int n)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void) hipGetLastError(); ndev = 0; }
+    for (int i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= ndev) { fa_set_error("libfiasco_amd: no HIP device %d", ids[i]); return 0; }
+    fiasco_amd_release_memory();
+    pthread_mutex_lock(&g_dev_lock);
+    g_devices.clear();
+    g_device_explicit = -1;
+    for (int i = 0; i < n; i++) g_devices.push_back(ids[i]);
+    while (g_dev_state.size() < g_devices.size()) g_dev_state.push_back(g_dev_state.empty() ? &g_state0 : new DevState);
+    pthread_mutex_unlock(&g_dev_lock);
+    return 1;
+}
+
+/* one process per GPU: bind this process's coder to a device of the node */
+extern "C" int fiasco_amd_set_device(int device)
+{
+    int cur = -1;
+    /* the slab pools hold memory of the device they were allocated on: never carry them over */
+    if (hipGetDevice(&cur) != hipSuccess || cur != device || g_devices.size() != 1) fiasco_amd_release_memory();
+    if (hipSetDevice(device) != hipSuccess) {
+        fa_set_error("libfiasco_amd: cannot select HIP device %d", device);
+        return 0;
+    }
+    pthread_mutex_lock(&g_dev_lock);
+    g_device_explicit = device;
+    g_devices.clear();                              /* resolved again by the next call */
+    pthread_mutex_unlock(&g_dev_lock);
+    return 1;
+}
+
+extern "C" void fiasco_amd_release_memory(void)
+{
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (size_t k = 0; k < g_dev_state.size(); k++) {
+        DevState *st = g_dev_state[k];
+        if (st->free.empty()) continue;
+        if (k < g_devices.size() && g_devices[k] >= 0 && g_devices.size() > 1) (void) hipSetDevice(g_devices[k]);
+        for (size_t i = 0; i < st->free.size(); i++) (void) hipFree(st->free[i].base);
+        st->free.clear();
+    }
+    if (g_dev_state.empty()) {
+        for (size_t i = 0; i < g_state0.free.size(); i++) (void) hipFree(g_state0.free[i].base);
+        g_state0.free.clear();
+    }
+    if (have_cur && g_devices.size() > 1) (void) hipSetDevice(cur);
+}
+
+/* counters: the sum over the shares; kernel time and the largest automaton: the maximum (the shares run
+ * side by side, frames / kernel_ms stays the rate of the whole job) */
+extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out)
+{
+    *out = g_state0.stats;
+    for (size_t k = 1; k < g_dev_state.size(); k++) {
+        const fiasco_amd_stats &b = g_dev_state[k]->stats;
+        unsigned long long *o = (unsigned long long *) ((char *) out + sizeof(double));
+        const unsigned long long *v = (const unsigned long long *) ((const char *) &b + sizeof(double));
+        const size_t nw = (sizeof(fiasco_amd_stats) - sizeof(double)) / sizeof(unsigned long long);
+        const size_t imax = (offsetof(fiasco_amd_stats, states_max) - sizeof(double)) / sizeof(unsigned long long);
+        for (size_t i = 0; i < nw; i++) o[i] = i == imax ? (o[i] > v[i] ? o[i] : v[i]) : o[i] + v[i];
+        if (b.kernel_ms > out->kernel_ms) out->kernel_ms = b.kernel_ms;
+    }
+}
+extern "C" void fiasco_amd_reset_stats(void)
+{
+    memset(&g_state0.stats, 0, sizeof g_state0.stats);
+    for (size_t k = 1; k < g_dev_state.size(); k++) memset(&g_dev_state[k]->stats, 0, sizeof(fiasco_amd_stats));
+}
+
+struct MultiStaged {
+    unsigned n = 0;
+    fa_job  *jobs = nullptr;
+    struct Part { std::vector<unsigned> idx; std::vector<fa_job> sub; void *staged = nullptr; int good = 0; };
+    std::vector<Part> parts;        /* one share: parts[0].staged works on jobs[] itself, nothing is copied */
+};
+
+/* run fn(share) for every share: share 0 on the calling thread, the others on threads of their own,
+ * each bound to its device and its DevState for the duration of the call */
+template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
+{
+    const size_t D = M->parts.size();
+    if (D == 1) { fn(0); return; }
+    struct Arg { Fn *fn; size_t k; };
+    std::vector<pthread_t> th(D);
+    std::vector<Arg> arg(D);
+    std::vector<char> started(D, 0);
+    auto body = [](void *p) -> void * {
+        Arg *a = (Arg *) p;
+        t_dev = g_dev_state[a->k];
+        if (g_devices[a->k] >= 0) (void) hipSetDevice(g_devices[a->k]);
+        (*a->fn)(a->k);
+        return nullptr;
+    };
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (size_t k = 1; k < D; k++) {
+        arg[k].fn = &fn; arg[k].k = k;
+        started[k] = pthread_create(&th[k], nullptr, body, &arg[k]) == 0;
+    }
+    arg[0].fn = &fn; arg[0].k = 0;
+    body(&arg[0]);                                  /* share 0 here (t_dev == &g_state0 already) */
+    for (size_t k = 1; k < D; k++) {
+        if (started[k]) pthread_join(th[k], nullptr);
+        else { body(&arg[k]); t_dev = &g_state0; }   /* no thread: one after the other */
+    }
+    t_dev = &g_state0;
+    if (have_cur) (void) hipSetDevice(cur);
+}
+
+extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
+{
+    resolve_devices();
+    MultiStaged *M = new MultiStaged;
+    M->n = n; M->jobs = jobs;
+    size_t D = g_devices.size();
+    if (D > n) D = n ? n : 1;
+    M->parts.resize(D);
+    if (D == 1) { M->parts[0].staged = core1_stage(n, jobs); return M; }
+    for (unsigned i = 0; i < n; i++) M->parts[i % D].idx.push_back(i);       /* round robin, SURVEY 8e */
+    for (size_t k = 0; k < D; k++) {
+        MultiStaged::Part &P = M->parts[k];
+        P.sub.resize(P.idx.size());
+        for (size_t j = 0; j < P.idx.size(); j++) P.sub[j] = jobs[P.idx[j]];
+    }
+    for_each_share(M, [&](size_t k) { MultiStaged::Part &P = M->parts[k]; P.staged = core1_stage((unsigned) P.sub.size(), P.sub.data()); });
+    for (size_t k = 0; k < D; k++)                                              /* what staging said about a job */
+        for (size_t j = 0; j < M->parts[k].idx.size(); j++) jobs[M->parts[k].idx[j]] = M->parts[k].sub[j];
+    return M;
+}
+
+extern "C" void fa_core_unstage(void *h)
+{
+    MultiStaged *M = (MultiStaged *) h;
+    if (!M) return;
+    for_each_share(M, [&](size_t k) { core1_unstage(M->parts[k].staged); });
+    delete M;
+}
+
+extern "C" int fa_core_submit(void *h)
+{
+    MultiStaged *M = (MultiStaged *) h;
+    if (!M) return 0;
+    if (M->parts.size() == 1) return core1_submit(M->parts[0].staged);
+    int ok = 1;
+    for (size_t k = 0; k < M->parts.size(); k++)                               /* inputs as the caller has them now */
+        for (size_t j = 0; j < M->parts[k].idx.size(); j++) {
+            fa_job &dst = M->parts[k].sub[j];
+            const fa_job &src = M->jobs[M->parts[k].idx[j]];
+            dst.image = src.image; dst.frame_type = src.frame_type; dst.past = src.past; dst.future = src.future;
+            dst.cp = src.cp; dst.wfa = src.wfa; dst.ycol_carry = src.ycol_carry;
+        }
+    for_each_share(M, [&](size_t k) { M->parts[k].good = core1_submit(M->parts[k].staged); });
+    for (size_t k = 0; k < M->parts.size(); k++) ok = ok && M->parts[k].good;
+    return ok;
+}
+
+extern "C" int fa_core_finish2(void *h, int resubmit)
+{
+    MultiStaged *M = (MultiStaged *) h;
+    if (!M) return 0;
+    if (M->parts.size() == 1) return core1_finish2(M->parts[0].staged, resubmit);
+    for_each_share(M, [&](size_t k) { M->parts[k].good = core1_finish2(M->parts[k].staged, resubmit); });
+    int good = 0;
+    for (size_t k = 0; k < M->parts.size(); k++) {
+        good += M->parts[k].good;
+        for (size_t j = 0; j < M->parts[k].idx.size(); j++) M->jobs[M->parts[k].idx[j]] = M->parts[k].sub[j];
+    }
+    return good;
+}
+
 extern "C" int fa_core_finish(void *h) { return fa_core_finish2(h, 0); }
 
 extern "C" int fa_core_run(void *h)
 {
     if (!fa_core_submit(h)) return 0;
     return fa_core_finish(h);
+}
+
+/* replacement inputs for a staged batch (a stream of batches over PCIe): one device only -- with several
+ * the caller stages the next batch instead (fiasco_amd_batch_upload() says so) */
+extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
+{
+    MultiStaged *M = (MultiStaged *) h;
+    return M && M->parts.size() == 1 ? core1_upload_buffer(M->parts[0].staged, bytes) : nullptr;
+}
+
+extern "C" int fa_core_upload_commit(void *h)
+{
+    MultiStaged *M = (MultiStaged *) h;
+    return M && M->parts.size() == 1 ? core1_upload_commit(M->parts[0].staged) : 0;
 }
 
 extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)

@@ -345,6 +345,53 @@ int fiasco_amd_batch_stats(const fiasco_amd_batch_t *b, unsigned i, unsigned ban
     return 1;
 }
 
+/* Decoded PSNR of frame i of a batch whose last pass succeeded: the finished automaton
+ * is decoded like `dfiasco -s 0` does (decode_image, codec/decoder.c:411-536, no smoothing -- the frame the
+ * coder itself would use as a reference) and compared with the input the way bin/pnmpsnr.c:36-163 compares
+ * two PNM files: both sides as bytes, clip((pixel >> 4) + 128) (lib/image.c gray_write), squared differences
+ * summed sequentially in float, 10 log10(255^2 / mean).  psnr_db[band] = +inf when the planes do not
+ * differ (pnmpsnr: "don't differ" below 1e-4).  For square gray frames that is pnmpsnr's figure to the
+ * last digit (tests/golden/MANIFEST.json "decoded_psnr").  For w x h frames the reference tool divides by
+ * w x w -- fiasco_image_get_height() returns the width, lib/image.c:134 -- so its mean is ours x h / w for
+ * h <= w (the tests convert); here the mean is over the pixels of the image.  For colour frames the three
+ * planes Y, Cb, Cr are compared as they are, without pnmpsnr's detour through RGB. */
+int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double psnr_db[3], double mse[3])
+{
+    const fa_image *orig;
+    fa_image *dec;
+    unsigned band, nb;
+    if (!b || i >= b->n || !b->jobs[i].status || !b->jobs[i].wfa) {
+        fa_set_error("fiasco_amd_batch_decode_psnr: frame %u has no finished automaton", i);
+        return 0;
+    }
+    if (b->jobs[i].frame_type != FA_I_FRAME) {
+        fa_set_error("fiasco_amd_batch_decode_psnr: intra frames only (a P/B frame needs its reference frames)");
+        return 0;
+    }
+    orig = b->jobs[i].image;
+    dec = fa_decode_image(orig->width, orig->height, b->jobs[i].wfa, orig->color);
+    if (!dec) return 0;
+    nb = orig->color ? 3 : 1;
+    for (band = 0; band < 3; band++) { if (psnr_db) psnr_db[band] = 0; if (mse) mse[band] = 0; }
+    for (band = 0; band < nb; band++) {
+        const int16_t *p = orig->pixels[band], *q = dec->pixels[band];
+        const size_t n = (size_t) orig->width * orig->height;
+        size_t k;
+        float norm = 0;                                 /* real_t, summed in file order (bin/pnmpsnr.c:92-101) */
+        for (k = 0; k < n; k++) {
+            int a = (p[k] >> 4) + 128, c = (q[k] >> 4) + 128;
+            a = a < 0 ? 0 : a > 255 ? 255 : a;
+            c = c < 0 ? 0 : c > 255 ? 255 : c;
+            norm += (float) ((a - c) * (a - c));
+        }
+        norm /= (float) n;
+        if (mse) mse[band] = norm;
+        if (psnr_db) psnr_db[band] = norm > 1e-4 ? 10 * log(255.0 * 255.0 / norm) / log(10.0) : INFINITY;
+    }
+    fa_image_free(dec);
+    return 1;
+}
+
 void fiasco_amd_batch_free(fiasco_amd_batch_t *b)
 {
     unsigned i;
@@ -542,7 +589,8 @@ int fiasco_amd_batch_upload(fiasco_amd_batch_t *b, const unsigned char *const *p
     buf = fa_core_upload_buffer(b->staged, total * sizeof(int16_t));
     if (!buf) {
         free(off); free(nims);
-        fa_set_error("No staging memory for %.1f MiB of frames.", total * 2 / 1048576.0);
+        fa_set_error("No staging memory for %.1f MiB of frames (replacing staged inputs needs a single device).",
+                     total * 2 / 1048576.0);
         return 0;
     }
     nt = b->n / 8;

@@ -153,6 +153,12 @@ int  fiasco_amd_batch_upload(fiasco_amd_batch_t *batch, const unsigned char *con
  * Returns 1, or 0 when i/band are out of range or the frame failed.                     */
 int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigned band,
                             float *costs, float *err, unsigned *width, unsigned *height);
+
+/* Decoded PSNR of frame i after a successful pass (reference tools: dfiasco -s 0 followed
+ * by pnmpsnr, codec/decoder.c:411-536 and bin/pnmpsnr.c:36-163): the automaton is decoded without
+ * smoothing and compared with the input as bytes.  psnr_db / mse: one entry per band (gray: [0] only; may
+ * be NULL).  Intra frames only.  1 ok / 0 + error message. */
+int  fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *batch, unsigned i, double psnr_db[3], double mse[3]);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
 
 /* ---- sequences across processes (one process per GPU) ---------------------------------------

@@ -62,9 +62,17 @@ int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int nar
  * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */
 const char *fa_core_name(void);
 
-/* Select the HIP device this process encodes on (one process per GPU; default 0).
- * Returns 1 on success, 0 + error message otherwise. */
+/* Devices.  Frames are independent units: every batch entry -- fiasco_amd_encode_batch(),
+ * the staged batches, fiasco_coder() on an all-intra stream or a video (its groups of pictures) -- spreads
+ * its frames round robin over the devices of the process, one host thread + stream + slab pool per
+ * device, results in input order, no collective.  The devices are: FIASCO_AMD_DEVICES="0,1,..." from the
+ * environment if set; else what fiasco_amd_set_devices() chose; else the ONE device of
+ * fiasco_amd_set_device() (one process per GPU: the multi-process harness); else every visible device.
+ * An id may be listed twice (two shares on one GPU).  Replacement of staged inputs
+ * (fiasco_amd_batch_upload) needs a single device.  All return 1 on success, 0 + error message. */
 int fiasco_amd_set_device(int device);
+int fiasco_amd_set_devices(const int *ids, int n);      /* n = 0: back to the automatic choice */
+int fiasco_amd_device_count(void);                      /* shares a batch is split into */
 
 /* The launcher keeps the per-frame HBM slabs of finished calls in a process-wide pool
  * (hipMalloc of hundreds of MB per frame is slow); this returns the pool to the driver. */

@@ -5,12 +5,18 @@
 # /root/reference (nothing is copied into this repo) into oracle/_ref/:
 #     oracle/_ref/libfiasco_ref.so   reference library (lib/ input/ output/ codec/)
 #     oracle/_ref/cfiasco_ref        reference CLI     (bin/cwfa.c + params + getopt)
+#     oracle/_ref/dfiasco_ref        reference decoder CLI (bin/dwfa.c) and
+#     oracle/_ref/pnmpsnr_ref        PSNR tool (bin/pnmpsnr.c): decoded-PSNR known answers
 #     oracle/_ref/libfiasco_ref_big.so / cfiasco_ref_big
-#                                    "limits extension" variant:
-#                                    -DMAXSTATES/-DMAXLEVEL cannot be overridden from the
-#                                    command line (plain #define in codec/wfa.h), so the
-#                                    big variant is NOT built here; 4K parity is declared
-#                                    "unpinned by a local reference build" in DESIGN.md.
+#                                    "limits extension" variant: MAXSTATES 6000 -> 30000,
+#                                    MAXLEVEL 22 -> 26, init_tree_model() uses entry 21 of its two count
+#                                    tables for levels >= 22.  MAXSTATES / MAXLEVEL are plain #defines in
+#                                    codec/wfa.h and cannot be overridden from the command line, so this
+#                                    variant is compiled from a THROW-AWAY copy of the sources under
+#                                    /tmp that is patched by the three sed lines below and deleted again;
+#                                    only the objects and the two binaries land in oracle/_ref/.  It pins
+#                                    what the stock reference cannot run at all: 4K (level 24) and 1080p
+#                                    colour at the CLI defaults (> 6000 states), tests/golden/MANIFEST_BIG.json.
 #
 # The sources include "config.h" unconditionally.  That file is autoconf output; it is
 # produced here by running the reference's own pre-generated `configure` script OUT OF
@@ -78,4 +84,46 @@ for f in cwfa params binerror getopt getopt1; do
     cli+=("$o")
 done
 gcc -fcommon -o "$OUT/cfiasco_ref" "${cli[@]}" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
-echo "ref_build: built $OUT/libfiasco_ref.so and $OUT/cfiasco_ref"
+# the reference's own decoder front end and PSNR tool (bin/dwfa.c, bin/pnmpsnr.c): they pin the decoded-PSNR
+# figures of tests/golden/MANIFEST.json ("decoded_psnr": dfiasco -s 0, then pnmpsnr)
+gcc $CFLAGS -I"$REF/bin" -c "$REF/bin/dwfa.c" -o "$OUT/obj/bin_dwfa.o"
+gcc $CFLAGS -I"$REF/bin" -c "$REF/bin/pnmpsnr.c" -o "$OUT/obj/bin_pnmpsnr.o"
+gcc -fcommon -o "$OUT/dfiasco_ref" "$OUT/obj/bin_dwfa.o" "$OUT/obj/bin_params.o" "$OUT/obj/bin_binerror.o" \
+    "$OUT/obj/bin_getopt.o" "$OUT/obj/bin_getopt1.o" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
+gcc -fcommon -o "$OUT/pnmpsnr_ref" "$OUT/obj/bin_pnmpsnr.o" "$OUT/obj/bin_binerror.o" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
+echo "ref_build: built $OUT/libfiasco_ref.so, $OUT/cfiasco_ref, dfiasco_ref and pnmpsnr_ref"
+
+# ---- limits extension: patched throw-away copy, same flags ----
+if [ -z "${FIASCO_SKIP_REF_BIG:-}" ] && { [ ! -x "$OUT/cfiasco_ref_big" ] || [ "$0" -nt "$OUT/cfiasco_ref_big" ]; }; then
+    TMPSRC=$(mktemp -d /tmp/fiasco_ref_big.XXXXXX)
+    trap 'rm -rf "$TMPSRC"' EXIT
+    cp -r "$REF/lib" "$REF/input" "$REF/output" "$REF/codec" "$REF/bin" "$REF/fiasco.h" "$TMPSRC/"
+    sed -i -e 's/^#define MAXSTATES 6000$/#define MAXSTATES 30000/' \
+           -e 's/^#define MAXLEVEL  22 *$/#define MAXLEVEL  26/' "$TMPSRC/codec/wfa.h"
+    sed -i -e 's/counts_1 \[level\];/counts_1 [level < 22 ? level : 21];/' \
+           -e 's/counts_0 \[level\] + counts_1 \[level\];/counts_0 [level < 22 ? level : 21] + counts_1 [level < 22 ? level : 21];/' \
+           "$TMPSRC/codec/bintree.c"
+    # the patch must have taken (a changed upstream file would otherwise give a silently stock build)
+    grep -q '^#define MAXSTATES 30000$' "$TMPSRC/codec/wfa.h" && grep -q '^#define MAXLEVEL  26$' "$TMPSRC/codec/wfa.h" \
+        && [ "$(grep -c 'level < 22 ? level : 21' "$TMPSRC/codec/bintree.c")" = 2 ] \
+        || { echo "ref_build: the limits-extension patch did not apply" >&2; exit 1; }
+    mkdir -p "$OUT/obj_big"
+    BFLAGS="-O2 -g -fcommon -fPIC -w -DHAVE_CONFIG_H -I$OUT/cfg -I$TMPSRC -I$TMPSRC/lib -I$TMPSRC/input -I$TMPSRC/output -I$TMPSRC/codec -DFIASCO_SHARE=\"$REF/data\""
+    bobjs=()
+    for f in "$TMPSRC"/lib/*.c "$TMPSRC"/input/*.c "$TMPSRC"/output/*.c "$TMPSRC"/codec/*.c; do
+        o="$OUT/obj_big/$(basename "$(dirname "$f")")_$(basename "${f%.c}").o"
+        gcc $BFLAGS -c "$f" -o "$o"
+        bobjs+=("$o")
+    done
+    gcc -shared -fcommon -o "$OUT/libfiasco_ref_big.so" "${bobjs[@]}" -lm
+    bcli=()
+    for f in cwfa params binerror getopt getopt1; do
+        o="$OUT/obj_big/bin_$f.o"
+        gcc $BFLAGS -I"$TMPSRC/bin" -c "$TMPSRC/bin/$f.c" -o "$o"
+        bcli+=("$o")
+    done
+    gcc -fcommon -o "$OUT/cfiasco_ref_big" "${bcli[@]}" -L"$OUT" -lfiasco_ref_big -Wl,-rpath,'$ORIGIN' -lm
+    rm -rf "$TMPSRC"; trap - EXIT
+    echo "limits_extension: MAXSTATES 30000, MAXLEVEL 26, init_tree_model entry 21 for levels >= 22 (sed patch of a /tmp copy)" >> "$OUT/BUILD_INFO"
+    echo "ref_build: built $OUT/libfiasco_ref_big.so and $OUT/cfiasco_ref_big (limits extension)"
+fi

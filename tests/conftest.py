@@ -73,7 +73,7 @@ class Inputs:
             return self.cache[name]
         import synth
         ent = self.man["inputs"][name]
-        if ent["file"]:
+        if ent.get("file"):
             d = open(os.path.join(GOLDEN, ent["file"]), "rb").read()
         else:
             a = ent["args"]
@@ -100,6 +100,18 @@ class Inputs:
 @pytest.fixture(scope="session")
 def inputs(manifest, tmp_path_factory):
     return Inputs(manifest, tmp_path_factory.mktemp("inputs"))
+
+
+@pytest.fixture(scope="session")
+def manifest_big():
+    """Known answers of the limits-extension reference build (oracle/ref_build.sh: MAXSTATES 30000,
+    MAXLEVEL 26; tests/golden/make_golden_big.py): what the stock reference cannot encode."""
+    return json.load(open(os.path.join(GOLDEN, "MANIFEST_BIG.json")))
+
+
+@pytest.fixture(scope="session")
+def inputs_big(manifest_big, tmp_path_factory):
+    return Inputs(manifest_big, tmp_path_factory.mktemp("inputs_big"))
 
 
 def options_from_args(lib, args):

@@ -29,7 +29,12 @@ import synth  # noqa: E402
 from fuzz_parity import random_image  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "cfiasco_ref")
+# FUZZ_HUGE=1: images beyond 2048 pixels (up to 2600 x 1700) and the state budget of the declared limits
+# extension -- against the limits-extension build of the reference (oracle/ref_build.sh:
+# MAXSTATES 30000, MAXLEVEL 26), the oracle under the same limits
+REF_BIG = os.path.join(ROOT, "oracle", "_ref", "cfiasco_ref_big")
 ORA = os.path.join(ROOT, "oracle", "cfiasco_oracle")
+HUGE = os.environ.get("FUZZ_HUGE") == "1"
 
 
 def one(seed):
@@ -53,6 +58,11 @@ def one(seed):
             "--rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])), "--dc-rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])),
             "--chroma-qfactor", str(rng.choice([1.0, 2.0, 3.5])), "--chroma-dictionary", str(rng.choice([1, 5, 40, 63, 100])),
             "--tiling-exponent", str(int(rng.integers(0, 6))), "--pattern", pattern] + extra
+    ref, ora_extra = REF, []
+    if HUGE:
+        ref, ora_extra = REF_BIG, ["--limit-states", "30000", "--limit-level", "26"]
+        colour = bool(rng.integers(0, 6) == 0)
+        nfr = int(rng.choice([1, 1, 1, 2]))
     with tempfile.TemporaryDirectory() as td:
         names = []
         first = random_image(rng, colour)
@@ -74,11 +84,11 @@ def one(seed):
                 (synth.write_ppm if colour else synth.write_pgm)(p, a)
             names.append(p)
         env = dict(os.environ, FIASCO_DATA="/root/reference/data")
-        r = subprocess.run([REF, "--progress-meter", "0"] + args + ["-o", os.path.join(td, "r.fco")] + names,
+        r = subprocess.run([ref, "--progress-meter", "0"] + args + ["-o", os.path.join(td, "r.fco")] + names,
                            env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         if r.returncode < 0 or r.returncode >= 128:
             return seed, "refcrash", args
-        o = subprocess.run([ORA, "--progress-meter", "0"] + args + ["-o", os.path.join(td, "o.fco")] + names,
+        o = subprocess.run([ORA, "--progress-meter", "0"] + ora_extra + args + ["-o", os.path.join(td, "o.fco")] + names,
                            env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         if r.returncode != 0 or o.returncode != 0:
             return seed, ("bothfail" if r.returncode != 0 and o.returncode != 0 else "MISMATCH rc %d/%d" % (r.returncode, o.returncode)), args

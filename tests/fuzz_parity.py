@@ -28,6 +28,11 @@ def random_image(rng, colour):
     big = int(os.environ.get("FUZZ_BIG", "0"))          # FUZZ_BIG=1: sizes up to 1000 x 800
     w = int(rng.integers(16, 500 if big else 200)) * 2
     h = int(rng.integers(16, 400 if big else 160)) * 2
+    if os.environ.get("FUZZ_HUGE") == "1":              # beyond the stock reference: one side > 2048 (level >= 23)
+        w = int(rng.integers(1030, 1300)) * 2
+        h = int(rng.integers(100, 850)) * 2
+        if rng.integers(0, 3) == 0:
+            w, h = h, w
     kind = int(rng.integers(0, 5))
     y, x = np.mgrid[0:h, 0:w].astype(np.float64)
     def plane():

@@ -101,7 +101,7 @@ def pmc_traffic(frames, w, h):
     FETCH_SIZE / WRITE_SIZE, separate runs of this same command), committed under profiles/.
     Counters cannot be collected from inside the timed run; the figure is reported only for
     the workload it was measured on."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

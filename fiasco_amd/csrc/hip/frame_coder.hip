@@ -478,6 +478,35 @@ __device__ __forceinline__ int qac_shift(int index)
     return n;
 }
 
+/* Out-of-line functions get the frame descriptor through a generic reference, so every table
+ * pointer they read is per-lane data to the compiler (64-bit address arithmetic in VGPRs for
+ * each access).  The pointers ARE uniform: moving them to scalar registers leaves one 32-bit
+ * lane offset per access. */
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ GLOBAL_AS T *uniform_ptr(T *p)
+{
+    unsigned long long v = (unsigned long long) p;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    /* known to be HBM (never LDS/scratch): global_load with a scalar base, not flat_load */
+    return (GLOBAL_AS T *) (((unsigned long long) hi << 32) | lo);
+}
+
+/* element i of a table behind a scalar base: the byte offset is formed in 32 bits so that
+ * the access is `global_load v, v_off, s[base:base+1]` (tables are < 4 GB apart from gram,
+ * which is not accessed this way) */
+template <typename T>
+__device__ __forceinline__ T ldg(GLOBAL_AS const T *base, unsigned i)
+{
+    return *(GLOBAL_AS const T *) ((GLOBAL_AS const char *) base + i * (unsigned) sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ void stg(GLOBAL_AS T *base, unsigned i, T v)
+{
+    *(GLOBAL_AS T *) ((GLOBAL_AS char *) base + i * (unsigned) sizeof(T)) = v;
+}
+
 /* ------------------------------------------------------------------ table access */
 
 /* Gram tables, two layouts (frame_coder.h): full symmetric P x P per level, or -- FC_GRAM_TRI,
@@ -602,7 +631,7 @@ __device__ __forceinline__ void gram_flush(const DevFrame &, Sh &, int) { }
 
 __device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int upto)
 {
-    const int tid = threadIdx.x, P = F.P;
+    const int tid = threadIdx.x, P = __builtin_amdgcn_readfirstlane(F.P);
     int flim = sh.flim;
 #if FC_SPEC
     if (sh.sl.role > 0) return;      /* a verifier reads what its own states have in their own rows */
@@ -611,19 +640,23 @@ __device__ void gram_flush(const DevFrame &__restrict__ F, Sh &__restrict__ sh, 
     __syncthreads();                                        /* the rows are complete */
     while (upto - flim >= GRAM_FB) {
         for (int q = 0; q < F.NL; q++) {
-            float *G = GRAM(F, q);
+            /* (a level is P x P floats, < 4 GB: 32-bit element offsets behind a scalar base) */
+            GLOBAL_AS float *G = uniform_ptr(GRAM(F, q));
             for (int t = tid; t < flim + GRAM_FB; t += B) {
                 if (t < flim) {
                     float v[GRAM_FB];
 #pragma unroll
-                    for (int j = 0; j < GRAM_FB; j++) v[j] = G[(size_t) (flim + j) * P + t];
-                    float4 *dst = (float4 *) (G + (size_t) t * P + flim);
+                    for (int j = 0; j < GRAM_FB; j++) v[j] = ldg((GLOBAL_AS const float *) G, (unsigned) ((flim + j) * P + t));
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    GLOBAL_AS f4 *dst = (GLOBAL_AS f4 *) ((GLOBAL_AS char *) G + (unsigned) (t * P + flim) * 4u);
 #pragma unroll
-                    for (int j = 0; j < GRAM_FB / 4; j++)
-                        dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+                    for (int j = 0; j < GRAM_FB / 4; j++) {
+                        const f4 w = { v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3] };
+                        dst[j] = w;
+                    }
                 } else {
                     for (int j = t - flim + 1; j < GRAM_FB; j++)
-                        G[(size_t) t * P + flim + j] = G[(size_t) (flim + j) * P + t];
+                        stg(G, (unsigned) (t * P + flim + j), ldg((GLOBAL_AS const float *) G, (unsigned) ((flim + j) * P + t)));
                 }
             }
         }
@@ -669,35 +702,6 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
 
 /* states that can own tables: chroma states are all auxiliary (codec/subdivide.c:433-436) */
 __device__ __forceinline__ int table_states(const Sh &sh) { return sh.band ? sh.ystates : sh.states; }
-
-/* Out-of-line functions get the frame descriptor through a generic reference, so every table
- * pointer they read is per-lane data to the compiler (64-bit address arithmetic in VGPRs for
- * each access).  The pointers ARE uniform: moving them to scalar registers leaves one 32-bit
- * lane offset per access. */
-#define GLOBAL_AS __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ GLOBAL_AS T *uniform_ptr(T *p)
-{
-    unsigned long long v = (unsigned long long) p;
-    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
-    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
-    /* known to be HBM (never LDS/scratch): global_load with a scalar base, not flat_load */
-    return (GLOBAL_AS T *) (((unsigned long long) hi << 32) | lo);
-}
-
-/* element i of a table behind a scalar base: the byte offset is formed in 32 bits so that
- * the access is `global_load v, v_off, s[base:base+1]` (tables are < 4 GB apart from gram,
- * which is not accessed this way) */
-template <typename T>
-__device__ __forceinline__ T ldg(GLOBAL_AS const T *base, unsigned i)
-{
-    return *(GLOBAL_AS const T *) ((GLOBAL_AS const char *) base + i * (unsigned) sizeof(T));
-}
-template <typename T>
-__device__ __forceinline__ void stg(GLOBAL_AS T *base, unsigned i, T v)
-{
-    *(GLOBAL_AS T *) ((GLOBAL_AS char *) base + i * (unsigned) sizeof(T)) = v;
-}
 
 /* the automaton arrays of a frame behind uniform global pointers */
 struct AutoTabs {
@@ -833,13 +837,17 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
  * sh.pixels (NA and 2 NA for a whole block; fewer for the residual of a predicted range) */
 __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to, int na, int n4)
 {
-    const int tid = threadIdx.x, P = F.P;
-    float *const D5 = ACT_D5(F, sh);
+    const int tid = threadIdx.x, P = __builtin_amdgcn_readfirstlane(F.P);
+    /* tables behind scalar bases: global_load / global_store with a 32-bit lane offset (through the generic
+     * frame reference of this out-of-line code they would be flat_ instructions) */
+    GLOBAL_AS float *const D5 = uniform_ptr(ACT_D5(F, sh));
+    GLOBAL_AS const float *const imgT = uniform_ptr((const float *) F.imgT);
+    GLOBAL_AS const uint8_t *const dtype = uniform_ptr((const uint8_t *) F.domain_type);
     for (int s = from + tid; s < to; s += B) {
-        if (DEAD(sh, s) || !F.domain_type[s]) continue;
+        if (DEAD(sh, s) || !ldg(dtype, (unsigned) s)) continue;
         float v[32];
 #pragma unroll
-        for (int k = 0; k < 32; k++) v[k] = F.imgT[(size_t) k * P + s];
+        for (int k = 0; k < 32; k++) v[k] = ldg(imgT, (unsigned) (k * P + s));
         /* two addresses per step: packed fp32 multiply and add (v_pk_mul_f32 / v_pk_add_f32,
          * each half rounded like the scalar op; no fused multiply-add), pixels read in pairs */
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -851,8 +859,8 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
                 f2 vv = { v[k], v[k] };
                 ip = ip + px * vv;
             }
-            D5[(size_t) a * P + s] = ip.x;
-            if (a + 1 < na) D5[(size_t) (a + 1) * P + s] = ip.y;
+            stg(D5, (unsigned) (a * P + s), ip.x);
+            if (a + 1 < na) stg(D5, (unsigned) ((a + 1) * P + s), ip.y);
         }
 #if FC_VARIANT_BIG
         if (F.gl0 < F.images_level) {
@@ -884,6 +892,7 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     {   /* all pixel loads of the lane in flight: unconditional loads at clamped coordinates,
          * the outside of the image is zeroed afterwards (codec/subdivide.c:504-541) */
         constexpr int NIT = FC_PIXELS / B;
+        GLOBAL_AS const int16_t *const gplane = uniform_ptr(plane);      /* a plane is < 2^31 pixels */
         const int width = F.width, height = F.height;
         int raw[NIT];
         bool inside[NIT];
@@ -899,7 +908,7 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
             const int x = x0 + (int) xo, y = y0 + (int) yo;
             inside[it] = i < npx && y < height && x < width;
             const int xc = x < width ? x : width - 1, yc = y < height ? y : height - 1;
-            raw[it] = plane[(size_t) yc * width + xc];
+            raw[it] = ldg(gplane, (unsigned) (yc * width + xc));
         }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -980,8 +989,11 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
 #endif
     /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
      * depends on level l-1 of OTHER states only (codec/control.c:205-258) */
-    if (tid == B - 1) F.img[(size_t) s * F.NI] = F.final_d[s];
-    for (int i = tid; i < F.NI - 1; i += B) {
+    GLOBAL_AS float *const gimg = uniform_ptr(F.img);
+    GLOBAL_AS float *const gimgT = uniform_ptr(F.imgT);
+    const int NIu = __builtin_amdgcn_readfirstlane(F.NI);
+    if (tid == B - 1) stg(gimg, (unsigned) (s * NIu), F.final_d[s]);
+    for (int i = tid; i < NIu - 1; i += B) {
         int l = 31 - __clz(i + 2);                      /* offset 2^l - 1 + pos = i + 1 */
         int pos = i + 1 - ((1 << l) - 1);
         const int half = 1 << (l - 1), label = pos >= half;
@@ -990,13 +1002,13 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         float t[FC_MAXE + 1];
 #pragma unroll
         for (int a = 0; a <= FC_MAXE; a++)              /* all term images in flight */
-            t[a] = F.img[(size_t) sh.gs_idx[label][a] * F.NI + off];      /* dead slots: state 0 */
+            t[a] = ldg((GLOBAL_AS const float *) gimg, (unsigned) (sh.gs_idx[label][a] * NIu + off));      /* dead slots: state 0 */
         float v = 0;
 #pragma unroll
         for (int a = 0; a <= FC_MAXE; a++)
             if (a < n) v = (a == 0 && sh.gs_c[label]) ? t[0] : v + t[a] * sh.gs_w[label][a];
-        F.img[(size_t) s * F.NI + i + 1] = v;
-        if (l == il) F.imgT[(size_t) pos * P + s] = v;
+        stg(gimg, (unsigned) (s * NIu + i + 1), v);
+        if (l == il) stg(gimgT, (unsigned) (pos * P + s), v);
 #if FC_VARIANT_BIG
         if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) pos * P + s] = v;
 #endif
@@ -1117,13 +1129,16 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             }
         }
     }
-    for (int a = tid; a < F.NA; a += B) {
-        float vs[32], ip = 0;
+    {
+        GLOBAL_AS float *const gd5 = uniform_ptr(ACT_D5(F, sh));
+        for (int a = tid; a < F.NA; a += B) {
+            float vs[32], ip = 0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) vs[k] = F.imgT[(size_t) k * P + s];
+            for (int k = 0; k < 32; k++) vs[k] = ldg((GLOBAL_AS const float *) gimgT, (unsigned) (k * P + s));
 #pragma unroll
-        for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * vs[k];
-        ACT_D5(F, sh)[(size_t) a * P + s] = ip;
+            for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * vs[k];
+            stg(gd5, (unsigned) (a * P + s), ip);
+        }
     }
 #if FC_VARIANT_BIG
     if (F.gl0 < il)

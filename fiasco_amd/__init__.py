@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_c_options_set_models",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload", "fiasco_amd_set_devices", "fiasco_amd_device_count",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
@@ -98,6 +98,8 @@ class Library:
         L.fiasco_c_options_delete.argtypes = [c.c_void_p]
         L.fiasco_coder.argtypes = [c.POINTER(c.c_char_p), c.c_char_p, c.c_float, c.c_void_p]
         L.fiasco_coder.restype = c.c_int
+        L.fiasco_amd_c_options_set_models.argtypes = [c.c_void_p, c.c_char_p, c.c_char_p, c.c_char_p, c.c_char_p]
+        L.fiasco_amd_c_options_set_models.restype = c.c_int
         for name, args in [
             ("set_smoothing", [c.c_int]), ("set_frame_pattern", [c.c_char_p]),
             ("set_tiling", [c.c_int, c.c_uint]), ("set_basisfile", [c.c_char_p]),

@@ -574,6 +574,20 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         return 0;
     }
     if (job->wfa->basis_states > FC_MAXBASIS) { snprintf(why, n, "initial basis too large for the device coder"); return 0; }
+    /* the models fiasco.h can ask for -- and only those -- run on the device: `rle' pools, `adaptive'
+     * coefficients (the `constant' pool is the delta pool of a plain I frame and is never searched).  The
+     * others of the reference's registries exist in the CPU oracle only (no setter in fiasco.h reaches them,
+     * codec/options.c:77-80); never a silent CPU path: refused */
+    {
+        const bool delta_used = cp->prediction || job->frame_type != FA_I_FRAME;
+        if (cp->pool_kind != FA_POOL_RLE || (delta_used && cp->d_pool_kind != FA_POOL_RLE)
+            || cp->coeff_kind != FA_COEFF_ADAPTIVE || (delta_used && cp->d_coeff_kind != FA_COEFF_ADAPTIVE)) {
+            snprintf(why, n, "the device coder runs the `rle' domain pool and the `adaptive' coefficient model only "
+                             "(asked for: %s / %s, %s / %s)", fa_pool_name(cp->pool_kind), fa_pool_name(cp->d_pool_kind),
+                     fa_coeff_name(cp->coeff_kind), fa_coeff_name(cp->d_coeff_kind));
+            return 0;
+        }
+    }
     return 1;
 }
 

@@ -26,6 +26,7 @@ int main(int argc, char **argv)
     int optimize = 0, dict = 10000, cdict = 40, pmin = 6, pmax = 10, pred = 0, verbose = 1;
     int smooth = 70, progress = 2, rpf_m = 3, dc_m = 5, tile_e = 4;
     int lim_states = 0, lim_level = 0;
+    const char *m_pool = NULL, *m_dpool = NULL, *m_rpf = NULL, *m_drpf = NULL;
     static struct option lo[] = {
         {"output-name", 1, 0, 'o'}, {"quality", 1, 0, 'q'}, {"optimize", 1, 0, 'z'},
         {"verbose", 1, 0, 'V'}, {"title", 1, 0, 't'}, {"comment", 1, 0, 'c'},
@@ -38,6 +39,8 @@ int main(int argc, char **argv)
         /* parsed and dropped like bin/cwfa.c does (it never calls set_video_param) */
         {"half-pixel", 0, 0, 18}, {"cross-B-search", 0, 0, 18}, {"B-as-past-ref", 0, 0, 18},
         {"fps", 1, 0, 18},
+        /* the model names of c_options_t the reference CLI cannot set (fiasco_amd_c_options_set_models) */
+        {"domain-pool", 1, 0, 19}, {"d-domain-pool", 1, 0, 20}, {"rpf-model", 1, 0, 21}, {"d-rpf-model", 1, 0, 22},
         {0, 0, 0, 0}
     };
     int ch;
@@ -71,6 +74,10 @@ int main(int argc, char **argv)
         case 16: lim_states = atoi(optarg); break;
         case 17: lim_level = atoi(optarg); break;
         case 18: break;
+        case 19: m_pool = optarg; break;
+        case 20: m_dpool = optarg; break;
+        case 21: m_rpf = optarg; break;
+        case 22: m_drpf = optarg; break;
         default:
             fprintf(stderr, "usage: %s [-o out.fco] [-q quality] [-z level] [-V n] [--pattern p] "
                             "image.pgm ...\n", argv[0]);
@@ -105,6 +112,7 @@ int main(int argc, char **argv)
                                        pmax > 0 ? (unsigned) pmax : 0));
     CK(fiasco_c_options_set_quantization(o, rpf_m > 0 ? (unsigned) rpf_m : 0, to_range(rpf_r),
                                          dc_m > 0 ? (unsigned) dc_m : 0, to_range(dc_r)));
+    if (m_pool || m_dpool || m_rpf || m_drpf) CK(fiasco_amd_c_options_set_models(o, m_pool, m_dpool, m_rpf, m_drpf));
     n = argc - optind;
     inputs = (const char **) calloc((size_t) n + 1, sizeof *inputs);
     for (i = 0; i < n; i++) inputs[i] = argv[optind + i];

@@ -132,10 +132,17 @@ int fa_setup_params(const fa_options *op, float quality, unsigned width, unsigne
                      "path reads outside the reference frame).");
         return 0;
     }
-    if (strcasecmp(op->id_domain_pool, "rle") != 0 || strcasecmp(op->id_rpf_model, "adaptive") != 0
-        || strcasecmp(op->id_d_domain_pool, "rle") != 0 || strcasecmp(op->id_d_rpf_model, "adaptive") != 0) {
-        fa_set_error("Only the default `rle' domain pool and `adaptive' coefficient model are built.");
-        return 0;
+    {   /* alloc_domain_pool / alloc_coeff_model (codec/domain-pool.c:203-236, codec/coeff.c:107-131): an
+         * unknown name is a warning and the first entry of the table */
+        int known;
+        cp->pool_kind = fa_pool_kind_of(op->id_domain_pool, &known);
+        if (!known) fa_warning("Can't initialize domain pool '%s'. Using default value '%s'.", op->id_domain_pool, fa_pool_name(cp->pool_kind));
+        cp->d_pool_kind = fa_pool_kind_of(op->id_d_domain_pool, &known);
+        if (!known) fa_warning("Can't initialize domain pool '%s'. Using default value '%s'.", op->id_d_domain_pool, fa_pool_name(cp->d_pool_kind));
+        cp->coeff_kind = fa_coeff_kind_of(op->id_rpf_model, &known);
+        if (!known) fa_warning("Can't initialize coefficients model '%s'. Using default value '%s'.", op->id_rpf_model, fa_coeff_name(cp->coeff_kind));
+        cp->d_coeff_kind = fa_coeff_kind_of(op->id_d_rpf_model, &known);
+        if (!known) fa_warning("Can't initialize coefficients model '%s'. Using default value '%s'.", op->id_d_rpf_model, fa_coeff_name(cp->d_coeff_kind));
     }
     return 1;
 }

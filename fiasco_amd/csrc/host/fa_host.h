@@ -162,6 +162,25 @@ typedef struct fa_info {
     unsigned smoothing;
 } fa_info;
 
+/* ---------------- model registries (reference codec/domain-pool.c:188-236, codec/coeff.c:97-131) -----
+ * The reference names its domain pools and coefficient models by strings (c_options_t id_domain_pool,
+ * id_d_domain_pool, id_rpf_model, id_d_rpf_model; codec/options.c:77-80) and looks them up in two tables;
+ * an unknown name gives a warning and the FIRST entry of the table.  Same names, same order, same rule. */
+typedef enum fa_pool_kind {
+    FA_POOL_ADAPTIVE = 0,       /* "adaptive": quasi-arithmetic model per domain (qac), :259-498 */
+    FA_POOL_CONSTANT,           /* "constant": domain list {0}, no model, :504-544 */
+    FA_POOL_BASIS,              /* "basis": the adaptive pool over the basis states, :546-560 */
+    FA_POOL_UNIFORM,            /* "uniform": every usable state, uniform price, :562-615 */
+    FA_POOL_RLE,                /* "rle": the default, :621-879 */
+    FA_POOL_RLE_NO_CHROMA       /* "rle-no-chroma": rle whose list is not cut down for the chroma bands, :886-899 */
+} fa_pool_kind;
+typedef enum fa_coeff_kind { FA_COEFF_ADAPTIVE = 0, FA_COEFF_UNIFORM } fa_coeff_kind;
+/* name -> kind; *known = 0 and the table's first entry for a name the table does not hold (the caller warns) */
+fa_pool_kind  fa_pool_kind_of(const char *name, int *known);
+fa_coeff_kind fa_coeff_kind_of(const char *name, int *known);
+const char   *fa_pool_name(fa_pool_kind k);
+const char   *fa_coeff_name(fa_coeff_kind k);
+
 /* ---------------- parameters of one frame for the core coder ---------------- */
 typedef struct fa_cparams {
     float    price;                       /* 128*64/quality (codec/coder.c:164) */
@@ -181,6 +200,11 @@ typedef struct fa_cparams {
     int      delta_domains, normal_domains;
     unsigned search_range;
     int      half_pixel, cross_B_search;
+    /* the models (registries above): pool of the normal / of the delta approximation, their coefficient
+     * models.  Through fiasco.h only rle / rle / adaptive / adaptive can be had (no setter exists,
+     * codec/options.c:77-80); fiasco_amd_c_options_set_models() chooses the others. */
+    fa_pool_kind  pool_kind, d_pool_kind;
+    fa_coeff_kind coeff_kind, d_coeff_kind;
 } fa_cparams;
 
 /* result statistics of one coded band (root range), used for -V 2 style reporting */

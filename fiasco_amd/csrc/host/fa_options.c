@@ -289,3 +289,46 @@ int fiasco_c_options_set_title(fiasco_c_options_t *options, const char *title)
     op->title = dupstr(title);
     return 1;
 }
+
+
+/* ---------------- model registries (codec/domain-pool.c:188-236, codec/coeff.c:97-131) ---------------- */
+
+static const char *const pool_names[] = { "adaptive", "constant", "basis", "uniform", "rle", "rle-no-chroma", NULL };
+static const char *const coeff_names[] = { "adaptive", "uniform", NULL };
+
+fa_pool_kind fa_pool_kind_of(const char *name, int *known)
+{
+    unsigned n;
+    if (known) *known = 1;
+    for (n = 0; pool_names[n]; n++)
+        if (name && strcasecmp(pool_names[n], name) == 0) return (fa_pool_kind) n;
+    if (known) *known = 0;
+    return FA_POOL_ADAPTIVE;            /* "Using default value": the first entry */
+}
+
+fa_coeff_kind fa_coeff_kind_of(const char *name, int *known)
+{
+    unsigned n;
+    if (known) *known = 1;
+    for (n = 0; coeff_names[n]; n++)
+        if (name && strcasecmp(coeff_names[n], name) == 0) return (fa_coeff_kind) n;
+    if (known) *known = 0;
+    return FA_COEFF_ADAPTIVE;
+}
+
+const char *fa_pool_name(fa_pool_kind k) { return pool_names[k]; }
+const char *fa_coeff_name(fa_coeff_kind k) { return coeff_names[k]; }
+
+/* The four model names of c_options_t (codec/options.h:36-39): the reference has the fields and the
+ * registries but no fiasco_c_options_set_*() for them.  NULL keeps a name. */
+int fiasco_amd_c_options_set_models(fiasco_c_options_t *options, const char *domain_pool, const char *d_domain_pool,
+                                    const char *rpf_model, const char *d_rpf_model)
+{
+    fa_options *op = (fa_options *) fa_cast_options(options);
+    if (!op) return 0;
+    if (domain_pool)   { free(op->id_domain_pool);   op->id_domain_pool = dupstr(domain_pool); }
+    if (d_domain_pool) { free(op->id_d_domain_pool); op->id_d_domain_pool = dupstr(d_domain_pool); }
+    if (rpf_model)     { free(op->id_rpf_model);     op->id_rpf_model = dupstr(rpf_model); }
+    if (d_rpf_model)   { free(op->id_d_rpf_model);   op->id_d_rpf_model = dupstr(d_rpf_model); }
+    return 1;
+}

@@ -159,6 +159,15 @@ int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigne
  * smoothing and compared with the input as bytes.  psnr_db / mse: one entry per band (gray: [0] only; may
  * be NULL).  Intra frames only.  1 ok / 0 + error message. */
 int  fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *batch, unsigned i, double psnr_db[3], double mse[3]);
+
+/* The model names of the reference's c_options_t (codec/options.h:36-39; registries codec/domain-pool.c:188-236
+ * "adaptive", "constant", "basis", "uniform", "rle", "rle-no-chroma" and codec/coeff.c:97-131 "adaptive",
+ * "uniform").  The reference has the fields and the registries but no setter; through fiasco.h a coder
+ * always runs rle / rle / adaptive / adaptive.  NULL keeps a name; an unknown name is a warning and the
+ * first entry of its table, as in the reference.  The HIP device coder runs the default models only and
+ * refuses the others with a message (they are restated in the test oracle). */
+int  fiasco_amd_c_options_set_models(fiasco_c_options_t *options, const char *domain_pool, const char *d_domain_pool,
+                                     const char *rpf_model, const char *d_rpf_model);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);
 
 /* ---- sequences across processes (one process per GPU) ---------------------------------------

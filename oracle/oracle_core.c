@@ -51,16 +51,23 @@ typedef struct range {                  /* codec/cwfa.h:46-75 */
     int      prediction;
 } range;
 
-/* a domain pool: the "rle" model or the model-free "constant" pool {state 0}
- * (codec/domain-pool.c:504-544, 621-879) */
+/* a domain pool of the reference's registry (codec/domain-pool.c:188-236): "rle" (:621-879) and
+ * "rle-no-chroma" (:886-899), the model-free "constant" pool {state 0} (:504-544), "adaptive" (qac: one
+ * probability index per domain, :259-498), "basis" (the adaptive pool over the basis states, :546-560),
+ * "uniform" (every usable state at one price, :562-615).  m.n / m.max_domains / m.y_index and states[] serve
+ * the rle and the qac pools alike; qidx[] is qac_model_t.index. */
 typedef struct pool {
-    int       constant;
+    fa_pool_kind kind;
+    int       constant;     /* kind == FA_POOL_CONSTANT */
+    int       qac;          /* kind is FA_POOL_ADAPTIVE or FA_POOL_BASIS */
     rle_model m;
     int16_t  *states;       /* states[] of the lineage (see rle_model) */
+    int16_t  *qidx;         /* qac: probability index per domain */
 } pool;
 
 /* "adaptive" coefficient model (codec/coeff.c:190-326): counts per context, int16 */
 typedef struct cmodel {
+    int           uniform;      /* "uniform" model (codec/coeff.c:133-188): mantissa bits + 1 per weight, no counts */
     int16_t      *cnt, *tot;
     const fa_rpf *rpf, *dc_rpf;
     unsigned      size, nt;
@@ -193,15 +200,34 @@ static void init_matrix_tables(oc *c)
 
 /* ------------------------------------------------------------------ domain pools (domain-pool.c) */
 
-/* alloc_rle_domain_pool / alloc_const_domain_pool (:504-516, 632-676) */
-static void pool_init(oc *c, pool *pl, int constant)
+/* qac_append :448-464 */
+static int qac_append(pool *pl, unsigned state)
+{
+    if (pl->m.n >= pl->m.max_domains) return 0;
+    pl->qidx[pl->m.n] = pl->m.n > 0 ? pl->qidx[pl->m.n - 1] : 0;
+    pl->states[pl->m.n++] = (int16_t) state;
+    return 1;
+}
+
+/* alloc_domain_pool :203-236 and the six allocators behind it */
+static void pool_init(oc *c, pool *pl, fa_pool_kind kind)
 {
     unsigned m, s;
+    unsigned max_domains = c->cp->pool_max_states;
     memset(&pl->m, 0, sizeof pl->m);
-    pl->constant = constant;
-    if (constant) return;
+    pl->kind = kind;
+    pl->constant = kind == FA_POOL_CONSTANT;
+    pl->qac = kind == FA_POOL_ADAPTIVE || kind == FA_POOL_BASIS;
+    if (!max_domains) max_domains = 1;              /* "Using at least DC component." :221-226 */
+    if (pl->constant || kind == FA_POOL_UNIFORM) return;
+    if (pl->qac) {
+        pl->m.max_domains = (uint16_t) (kind == FA_POOL_BASIS ? c->w->basis_states : max_domains);
+        for (s = 0; s < c->w->basis_states; s++)
+            if (usedomain(c->w, (int) s)) qac_append(pl, s);
+        return;
+    }
     for (m = 0; m < MAXED + 1; m++) { pl->m.count[m] = 1; pl->m.total++; }
-    pl->m.max_domains = (uint16_t) c->cp->pool_max_states;
+    pl->m.max_domains = (uint16_t) max_domains;
     for (s = 0; s < c->w->basis_states; s++)
         if (usedomain(c->w, (int) s)) {
             if (pl->m.n < pl->m.max_domains) {
@@ -211,23 +237,32 @@ static void pool_init(oc *c, pool *pl, int constant)
         }
 }
 
-/* ->append: rle_append :832-852, default_append :957-962 (the constant pool takes everything) */
+/* ->append: rle_append :832-852, qac_append :448-464, default_append :957-962 (the constant and the uniform
+ * pool take everything) */
 static int pool_append(pool *pl, unsigned state)
 {
-    if (pl->constant) return 1;
+    if (pl->constant || pl->kind == FA_POOL_UNIFORM) return 1;
+    if (pl->qac) return qac_append(pl, state);
     if (pl->m.n >= pl->m.max_domains) return 0;
     pl->states[pl->m.n++] = (int16_t) state;
     return 1;
 }
 
 /* -1 terminated candidate list: the pool states plus the co-located Y state if usable
- * and not already present (rle_generate :707-735); the constant pool is {0} (:518-528).
- * Returns the list length. */
+ * and not already present (rle_generate :707-735, qac_generate :333-362); the constant pool is {0}
+ * (:518-528), the uniform pool every usable state (:578-590).  Returns the list length. */
 static unsigned pool_generate(oc *c, const pool *pl, int y_state, int16_t *out)
 {
     unsigned n, len = pl->m.n;
     int present = 0;
     if (pl->constant) { out[0] = 0; out[1] = -1; return 1; }
+    if (pl->kind == FA_POOL_UNIFORM) {
+        unsigned state;
+        for (state = 0, len = 0; state < c->w->states; state++)
+            if (usedomain(c->w, (int) state)) out[len++] = (int16_t) state;
+        out[len] = -1;
+        return len;
+    }
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
     memcpy(out, pl->states, len * sizeof(int16_t));
     for (n = 0; n < len; n++) if (out[n] == y_state) present = 1;
@@ -266,7 +301,31 @@ static float pool_bits(const oc *c, const pool *pl, const int16_t *domains, cons
     unsigned n = 0, e, last;
     float bits;
     if (pl->constant) return 0;
+    if (pl->kind == FA_POOL_UNIFORM) {
+        /* uniform_bits :592-615.  `- n * log2 (..)` negates the UNSIGNED n first: the price of the empty
+         * list is (2^32 - n) x log2((n - 1) / n), a large negative number -- reproduced, not repaired */
+        unsigned state, nn = 0;
+        for (state = 0; state < c->w->states; state++)
+            if (usedomain(c->w, (int) state)) nn++;
+        bits = (float) ((double) (0u - nn) * log2((double) ((float) (nn - 1) / (float) nn)));
+        if (used)
+            for (e = 0; used[e] != FA_NO_EDGE; e++) bits = (float) ((double) bits - log2(1.0 / nn));
+        return bits;
+    }
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
+    if (pl->qac) {
+        /* qac_bits :364-402 */
+        bits = 0;
+        for (e = 0; e < m->n; e++)
+            if (pl->states[e] != y_state) bits += c->m0[pl->qidx[e]];
+        if (y_state >= 0) bits += c->m0[m->y_index];
+        if (used)
+            for (e = 0; used[e] != FA_NO_EDGE; e++) {
+                if (domains[used[e]] == y_state) { bits -= c->m0[m->y_index]; bits += c->m1[m->y_index]; }
+                else { bits -= c->m0[pl->qidx[used[e]]]; bits += c->m1[pl->qidx[used[e]]]; }
+            }
+        return bits;
+    }
     if (used) {
         for (e = 0; used[e] != FA_NO_EDGE; e++)
             if (domains[used[e]] != y_state) sorted[n++] = used[e];
@@ -296,8 +355,32 @@ static void pool_update(oc *c, pool *pl, const int16_t *domains, const int16_t *
     rle_model *m = &pl->m;
     int state_0 = 0, state_y = 0;
     unsigned edge = 0;
-    if (pl->constant) return;
+    if (pl->constant || pl->kind == FA_POOL_UNIFORM) return;      /* default_update */
     if (y_state >= 0 && !usedomain(c->w, y_state)) y_state = -1;
+    if (pl->qac) {
+        /* qac_update :404-446 */
+        unsigned d;
+        int used_y = 0, y_is_domain = 0;
+        for (d = 0; d < m->n; d++) {
+            pl->qidx[d]++;
+            if (pl->states[d] == y_state) y_is_domain = 1;
+        }
+        if (used)
+            for (edge = 0; used[edge] != FA_NO_EDGE; edge++) {
+                if (domains[used[edge]] == y_state) {
+                    if (y_is_domain) pl->qidx[used[edge]]--;
+                    m->y_index >>= 1;
+                    used_y = 1;
+                } else {
+                    pl->qidx[used[edge]]--;
+                    pl->qidx[used[edge]] >>= 1;
+                }
+            }
+        if (y_state >= 0 && !used_y) m->y_index++;
+        for (d = 0; d < m->n; d++) if (pl->qidx[d] > 1020) pl->qidx[d] = 1020;
+        if (m->y_index > 1020) m->y_index = 1020;
+        return;
+    }
     if (used)
         for (edge = 0; used[edge] != FA_NO_EDGE; edge++) {
             if (domains[used[edge]] == 0) state_0 = 1;
@@ -326,7 +409,28 @@ static void pool_chroma(oc *c)
     pool *pl = &c->pl[0];
     rle_model *m = &pl->m;
     unsigned maxd = c->cp->chroma_max_states;
-    if (pl->constant) return;
+    /* default_chroma: the constant, uniform and rle-no-chroma pools stay as they are */
+    if (pl->constant || pl->kind == FA_POOL_UNIFORM || pl->kind == FA_POOL_RLE_NO_CHROMA) return;
+    if (pl->qac) {
+        /* qac_chroma :466-498: the most referenced states keep the index they had */
+        if (maxd < m->n) {
+            int16_t *dom = fa_compute_hits(c->w->basis_states, c->w->states - 1, maxd, c->w);
+            int16_t *st = (int16_t *) calloc(maxd + 1, sizeof(int16_t)), *ix = (int16_t *) calloc(maxd + 1, sizeof(int16_t));
+            unsigned n, nw, old;
+            for (n = 0; n < maxd && dom[n] >= 0; n++) st[n] = dom[n];
+            if (n < maxd) maxd = n;
+            free(dom);
+            for (old = 0, nw = 0; nw < maxd && old < m->n; old++)
+                if (pl->states[old] == st[nw]) ix[nw++] = pl->qidx[old];
+            memcpy(pl->states, st, maxd * sizeof(int16_t));
+            memcpy(pl->qidx, ix, maxd * sizeof(int16_t));
+            free(st); free(ix);
+            m->n = (uint16_t) maxd;
+        }
+        m->y_index = 0;
+        m->max_domains = m->n;
+        return;
+    }
     if (maxd < m->n) {
         int16_t *dom = fa_compute_hits(c->w->basis_states, c->w->states - 1, maxd, c->w);
         unsigned n;
@@ -349,6 +453,7 @@ static void coeff_init(oc *c)
     c->coeff_min = c->lc_min; c->coeff_max = c->lc_max;
     levels = c->coeff_max - c->coeff_min + 1;
     for (k = 0; k < 2; k++) {
+        c->cm[k].uniform = (k ? c->cp->d_coeff_kind : c->cp->coeff_kind) == FA_COEFF_UNIFORM;
         c->cm[k].rpf = rp[k][0]; c->cm[k].dc_rpf = rp[k][1];
         c->cm[k].size = levels * (1u << (1 + rp[k][0]->mantissa_bits)) + (1u << (1 + rp[k][1]->mantissa_bits));
         c->cm[k].nt = levels + 1;
@@ -381,6 +486,11 @@ static float coeff_bits(const oc *c, const cmodel *m, const float *wt, const int
     float bits = 0;
     const int16_t *ctx = coeff_ctx(c, m, level);
     unsigned e;
+    if (m->uniform) {                                    /* uniform_bits, codec/coeff.c:155-170 */
+        for (e = 0; states[e] != FA_NO_EDGE; e++)
+            bits += (states[e] ? m->rpf : m->dc_rpf)->mantissa_bits + 1;
+        return bits;
+    }
     for (e = 0; states[e] != FA_NO_EDGE; e++)
         if (states[e])
             bits -= log2(ctx[fa_rtob(wt[e], m->rpf)] / (float) m->tot[level - c->coeff_min + 1]);
@@ -395,6 +505,7 @@ static void coeff_update(oc *c, cmodel *m, const float *wt, const int16_t *state
 {
     int16_t *ctx = coeff_ctx(c, m, level);
     unsigned e;
+    if (m->uniform) return;                              /* uniform_update */
     for (e = 0; states[e] != FA_NO_EDGE; e++)
         if (states[e]) {
             ctx[fa_rtob(wt[e], m->rpf)]++;
@@ -1362,6 +1473,7 @@ static float nd_prediction(oc *c, float max_costs, float price, unsigned band, i
 /* the models a subdivide() call may have to go back to */
 typedef struct snapshot {
     rle_model pm[2];
+    int16_t  *qi[2];        /* qac pools: the probability indices (qac_model_duplicate, :318-331) */
     int16_t  *cbuf;
     unsigned *tm;
     unsigned  states;
@@ -1369,7 +1481,15 @@ typedef struct snapshot {
 
 static void snap_take(oc *c, snapshot *sn)
 {
+    unsigned k;
     sn->pm[0] = c->pl[0].m; sn->pm[1] = c->pl[1].m;
+    for (k = 0; k < 2; k++) {
+        sn->qi[k] = NULL;
+        if (c->pl[k].qac) {
+            sn->qi[k] = (int16_t *) malloc((c->pl[k].m.n + 1) * sizeof(int16_t));
+            memcpy(sn->qi[k], c->pl[k].qidx, c->pl[k].m.n * sizeof(int16_t));
+        }
+    }
     sn->cbuf = (int16_t *) malloc(c->cbuf_n * sizeof(int16_t));
     memcpy(sn->cbuf, c->cbuf, c->cbuf_n * sizeof(int16_t));
     sn->tm = NULL;
@@ -1383,7 +1503,10 @@ static void snap_take_tm(oc *c, snapshot *sn)
 
 static void snap_models(oc *c, const snapshot *sn)        /* pools + coefficient models */
 {
+    unsigned k;
     c->pl[0].m = sn->pm[0]; c->pl[1].m = sn->pm[1];
+    for (k = 0; k < 2; k++)
+        if (sn->qi[k]) memcpy(c->pl[k].qidx, sn->qi[k], sn->pm[k].n * sizeof(int16_t));
     memcpy(c->cbuf, sn->cbuf, c->cbuf_n * sizeof(int16_t));
 }
 
@@ -1392,7 +1515,7 @@ static void snap_tm(oc *c, const snapshot *sn)
     memcpy(c->tm, sn->tm, (size_t) 4 * c->ML * sizeof(unsigned));
 }
 
-static void snap_free(snapshot *sn) { free(sn->cbuf); free(sn->tm); }
+static void snap_free(snapshot *sn) { free(sn->cbuf); free(sn->tm); free(sn->qi[0]); free(sn->qi[1]); }
 
 /* predict_range, codec/prediction.c:96-208.  `entry`: models at the entry of the enclosing
  * subdivide() call, `states`: wfa->states at that time. */
@@ -1638,6 +1761,8 @@ static int encode_one(fa_job *job)
     c.tm = (unsigned *) calloc((size_t) 4 * c.ML + 4, sizeof(unsigned));
     c.pl[0].states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
     c.pl[1].states = (int16_t *) calloc(cap + 2, sizeof(int16_t));
+    c.pl[0].qidx = (int16_t *) calloc(cap + 2, sizeof(int16_t));
+    c.pl[1].qidx = (int16_t *) calloc(cap + 2, sizeof(int16_t));
     c.rem_num = (float *) calloc(cap + 2, sizeof(float));
     c.rem_den = (float *) calloc(cap + 2, sizeof(float));
     c.ipdo = (float *) calloc((size_t) (cap + 2) * MAXED, sizeof(float));
@@ -1662,8 +1787,8 @@ static int encode_one(fa_job *job)
     tree_init(c.tm + 2 * c.ML, c.tm + 3 * c.ML, c.ML);
     /* codec/coder.c:716-736: the delta pool is a second `rle' pool when residuals can occur,
      * else the constant pool */
-    pool_init(&c, &c.pl[0], 0);
-    pool_init(&c, &c.pl[1], !(cp->prediction || inter));
+    pool_init(&c, &c.pl[0], cp->pool_kind);
+    pool_init(&c, &c.pl[1], (cp->prediction || inter) ? cp->d_pool_kind : FA_POOL_CONSTANT);
     coeff_init(&c);
 
     if (!job->image->color) {
@@ -1728,7 +1853,7 @@ static int encode_one(fa_job *job)
     for (s = 0; s < cap; s++) free(c.gram[s]);
     for (l = 0; l < FA_CAP_LEVEL + 2; l++) { free(c.mt.fwd[l]); free(c.mt.bwd[l]); }
     free(c.images); free(c.ipis); free(c.ipis_alt); free(c.gram); free(c.pixels); free(c.tm);
-    free(c.pl[0].states); free(c.pl[1].states);
+    free(c.pl[0].states); free(c.pl[1].states); free(c.pl[0].qidx); free(c.pl[1].qidx);
     free(c.rem_num); free(c.rem_den); free(c.ipdo); free(c.used); free(c.dlist);
     free(c.cbuf);
     return job->status;

@@ -93,6 +93,38 @@ gcc -fcommon -o "$OUT/dfiasco_ref" "$OUT/obj/bin_dwfa.o" "$OUT/obj/bin_params.o"
 gcc -fcommon -o "$OUT/pnmpsnr_ref" "$OUT/obj/bin_pnmpsnr.o" "$OUT/obj/bin_binerror.o" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
 echo "ref_build: built $OUT/libfiasco_ref.so, $OUT/cfiasco_ref, dfiasco_ref and pnmpsnr_ref"
 
+# ---- the other entries of the reference's model registries (codec/domain-pool.c:188-236, codec/coeff.c:97-131)
+# fiasco.h has no setter for c_options_t.id_domain_pool / id_d_domain_pool / id_rpf_model / id_d_rpf_model: the
+# only way to make the reference run its "adaptive", "basis", "uniform" and "rle-no-chroma" pools or its
+# "uniform" coefficient model is another default in codec/options.c:77-80.  One throw-away copy of THAT FILE
+# per variant, four sed substitutions, linked with the stock objects: cfiasco_ref_<variant>.  They pin the
+# oracle's restatement of those models (tests/test_oracle_pins.py::test_model_registry_*).
+if [ -z "${FIASCO_SKIP_REF_MODELS:-}" ]; then
+    mkdir -p "$OUT/obj_models"
+    for v in "adaptive:adaptive:adaptive:adaptive:adaptive" "uniform:uniform:uniform:uniform:uniform" \
+             "basis:basis:rle:adaptive:uniform" "nochroma:rle-no-chroma:rle:adaptive:adaptive" "rleuni:rle:adaptive:uniform:adaptive"; do
+        IFS=: read -r name pool dpool rpf drpf <<< "$v"
+        [ -x "$OUT/cfiasco_ref_$name" ] && [ "$OUT/cfiasco_ref_$name" -nt "$0" ] && continue
+        TMPO=$(mktemp /tmp/fiasco_options_XXXXXX.c)
+        sed -e "s/id_domain_pool 	  = strdup (\"rle\")/id_domain_pool = strdup (\"$pool\")/" \
+            -e "s/id_d_domain_pool 	  = strdup (\"rle\")/id_d_domain_pool = strdup (\"$dpool\")/" \
+            -e "s/id_rpf_model 	  = strdup (\"adaptive\")/id_rpf_model = strdup (\"$rpf\")/" \
+            -e "s/id_d_rpf_model 	  = strdup (\"adaptive\")/id_d_rpf_model = strdup (\"$drpf\")/" \
+            "$REF/codec/options.c" > "$TMPO"
+        [ "$(grep -c "id_domain_pool = strdup (\"$pool\")\|id_d_domain_pool = strdup (\"$dpool\")\|id_rpf_model = strdup (\"$rpf\")\|id_d_rpf_model = strdup (\"$drpf\")" "$TMPO")" = 4 ] \
+            || { echo "ref_build: the model-name patch did not apply ($name)" >&2; rm -f "$TMPO"; exit 1; }
+        gcc $CFLAGS -c "$TMPO" -o "$OUT/obj_models/options_$name.o"
+        rm -f "$TMPO"
+        mobjs=()
+        for o in "${objs[@]}"; do
+            case "$o" in */codec_options.o) mobjs+=("$OUT/obj_models/options_$name.o");; *) mobjs+=("$o");; esac
+        done
+        gcc -shared -fcommon -o "$OUT/libfiasco_ref_$name.so" "${mobjs[@]}" -lm
+        gcc -fcommon -o "$OUT/cfiasco_ref_$name" "${cli[@]}" -L"$OUT" -lfiasco_ref_$name -Wl,-rpath,'$ORIGIN' -lm
+    done
+    echo "ref_build: built the model-registry variants cfiasco_ref_{adaptive,uniform,basis,nochroma,rleuni}"
+fi
+
 # ---- limits extension: patched throw-away copy, same flags ----
 if [ -z "${FIASCO_SKIP_REF_BIG:-}" ] && { [ ! -x "$OUT/cfiasco_ref_big" ] || [ "$0" -nt "$OUT/cfiasco_ref_big" ]; }; then
     TMPSRC=$(mktemp -d /tmp/fiasco_ref_big.XXXXXX)

@@ -1153,7 +1153,10 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
 #endif
     if (tid == 0) {
         const int E = sh.gs_n[0] + sh.gs_n[1];       /* tree children + edges of the new state */
-        sh.cnt.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * 2 * (s + 1) * F.NL;
+        /* B_gram = 5 * 4 * N * (1 + E) read + 5 * 4 * N written -- the five table levels of the
+         * reference (6..lc_max), one row per level, no mirrored entries.  (Until round 3 this counted what THIS
+         * layout writes, 8 * 6 * (s + 1): the cached level-5 row and the mirror; 6 % more bytes per frame.) */
+        sh.cnt.bytes_gram += (unsigned long long) (F.NL - 1) * 4ull * (s + 1) * (1 + E) + 4ull * (s + 1) * (F.NL - 1);
         sh.cnt.n_appends++;
     }
     gram_flush(F, sh, s + 1);

@@ -19,7 +19,7 @@ typedef struct fiasco_amd_stats {
     /* algorithmic bytes, summed per call from the coder's counters:
      *   bytes_mp   = sum over matching-pursuit calls of 4*D*(2+S) + 4*2^L
      *   bytes_img  = sum over init_range blocks of N*(128+4*NS) + 4*2^lc_max
-     *   bytes_gram = sum over appended states of 4*(NL-1)*(s+1)*(1+E) + 8*NL*(s+1)        */
+     *   bytes_gram = sum over appended states of 4*(NL-1)*(s+1)*(1+E) + 4*(NL-1)*(s+1)     */
     unsigned long long bytes_mp, bytes_img, bytes_gram;
     unsigned long long n_mp, n_steps, n_blocks, n_appends, n_fulleval;
     /* per-phase time summed over frames, 100 MHz ticks of workgroup lane 0:

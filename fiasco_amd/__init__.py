@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_c_options_set_models",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_batch_decode_plane", "fiasco_amd_c_options_set_models",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload", "fiasco_amd_set_devices", "fiasco_amd_device_count",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
@@ -300,6 +300,16 @@ class Batch:
         mse = err.value / w.value / h.value
         return {"costs": costs.value, "err": err.value, "width": w.value, "height": h.value,
                 "psnr_db": 10.0 * math.log10(255.0 * 255.0 / mse) if mse > 0 else float("inf")}
+
+    def decode_plane(self, i, band, width, height):
+        """fiasco_amd_batch_decode_plane: the decoded band as bytes (the payload of dfiasco -s 0's PGM for gray)."""
+        f = self.lib.L.fiasco_amd_batch_decode_plane
+        f.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_char_p]
+        f.restype = ctypes.c_int
+        buf = ctypes.create_string_buffer(width * height)
+        if not f(self.handle, i, band, buf):
+            raise FiascoError(self.lib.error_message())
+        return buf.raw
 
     def decode_psnr(self, i):
         """fiasco_amd_batch_decode_psnr: decoded PSNR in dB per band of frame i (what `dfiasco -s 0` +

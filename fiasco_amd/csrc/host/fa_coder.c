@@ -399,6 +399,34 @@ int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double
     return 1;
 }
 
+/* The decoded frame itself: band `band` of frame i as bytes, clip((pixel >> 4) + 128) in raster order
+ * (width x height of the input) -- for a gray frame exactly the payload of the PGM that `dfiasco -s 0 -o`
+ * writes (lib/image.c gray_write :449-483).  out must hold width * height bytes. */
+int fiasco_amd_batch_decode_plane(const fiasco_amd_batch_t *b, unsigned i, unsigned band, unsigned char *out)
+{
+    const fa_image *orig;
+    fa_image *dec;
+    size_t k, n;
+    if (!b || i >= b->n || !b->jobs[i].status || !b->jobs[i].wfa || !out) {
+        fa_set_error("fiasco_amd_batch_decode_plane: frame %u has no finished automaton", i);
+        return 0;
+    }
+    orig = b->jobs[i].image;
+    if (b->jobs[i].frame_type != FA_I_FRAME || band >= (orig->color ? 3u : 1u)) {
+        fa_set_error("fiasco_amd_batch_decode_plane: intra frames only, band < %u", orig->color ? 3u : 1u);
+        return 0;
+    }
+    dec = fa_decode_image(orig->width, orig->height, b->jobs[i].wfa, orig->color);
+    if (!dec) return 0;
+    n = (size_t) orig->width * orig->height;
+    for (k = 0; k < n; k++) {
+        int v = (dec->pixels[band][k] >> 4) + 128;
+        out[k] = (unsigned char) (v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+    fa_image_free(dec);
+    return 1;
+}
+
 void fiasco_amd_batch_free(fiasco_amd_batch_t *b)
 {
     unsigned i;

@@ -159,6 +159,9 @@ int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigne
  * smoothing and compared with the input as bytes.  psnr_db / mse: one entry per band (gray: [0] only; may
  * be NULL).  Intra frames only.  1 ok / 0 + error message. */
 int  fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *batch, unsigned i, double psnr_db[3], double mse[3]);
+/* ... and the decoded frame itself: one band as width x height bytes, clip((pixel >> 4) + 128) -- for a gray frame
+ * the payload of the PGM `dfiasco -s 0 -o` writes (lib/image.c:449-483). */
+int  fiasco_amd_batch_decode_plane(const fiasco_amd_batch_t *batch, unsigned i, unsigned band, unsigned char *out);
 
 /* The model names of the reference's c_options_t (codec/options.h:36-39; registries codec/domain-pool.c:188-236
  * "adaptive", "constant", "basis", "uniform", "rle", "rle-no-chroma" and codec/coeff.c:97-131 "adaptive",

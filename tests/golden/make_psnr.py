@@ -40,7 +40,11 @@ def main():
         r = subprocess.run([os.path.join(REFDIR, "pnmpsnr_ref"), src, dec], env=env, stderr=subprocess.PIPE, text=True)
         m = re.search(r"([0-9.]+) dB", r.stderr)
         assert m, r.stderr
-        out[name] = {"psnr_db": m.group(1), "tools": "dfiasco_ref -s 0 -o dec.pgm ref.fco; pnmpsnr_ref in.pgm dec.pgm"}
+        raw = open(dec, "rb").read()
+        w, h = [int(v) for v in raw.split(b"\n", 2)[1].split()]
+        import hashlib
+        out[name] = {"psnr_db": m.group(1), "decoded_md5": hashlib.md5(raw[len(raw) - w * h:]).hexdigest(),
+                     "tools": "dfiasco_ref -s 0 -o dec.pgm ref.fco; pnmpsnr_ref in.pgm dec.pgm; decoded_md5 = md5 of dec.pgm's pixel bytes"}
         print("%-14s %s dB" % (name, m.group(1)))
     man["decoded_psnr"] = out
     json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1)

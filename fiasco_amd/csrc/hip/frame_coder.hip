@@ -132,6 +132,20 @@
  * needs 3.4 x the time of the four waves together for one search, so a spine of three ranges costs what
  * three searches cost (519 .. 572 frames/s against 549 on the bench batch).
  * Kept as a build switch of the 256-thread default build for whoever wants to re-measure; off. */
+/* FC_D5T: the table of level-images_level dots is kept state-major, d5T[state][label][NA / 2] (address a ->
+ * label a & 1, column a >> 1), so that the first pass of op_ipis reads four consecutive slots of one term with
+ * ONE 16-byte load instead of four 4-byte gathers from four rows.  Same values, same sums. */
+#ifndef FC_D5T
+#define FC_D5T (!FC_VARIANT_BIG)
+#endif
+#if FC_D5T && FC_VARIANT_BIG
+#error "FC_D5T: the big build reads d5 rows as matching pursuit numerators"
+#endif
+#if FC_D5T
+#define D5_AT(P, NA, a, s) ((unsigned) (s) * (unsigned) (NA) + (unsigned) ((a) & 1) * ((unsigned) (NA) >> 1) + ((unsigned) (a) >> 1))
+#else
+#define D5_AT(P, NA, a, s) ((unsigned) (a) * (unsigned) (P) + (unsigned) (s))
+#endif
 #ifndef FC_SPINE
 #define FC_SPINE 0
 #endif
@@ -764,8 +778,15 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
         int cnt = 1 << delta;
         int slot0 = ((image + 1) << delta) - 1;
         int adr0 = address << delta;
+#if FC_D5T
+        const bool first = lv == il + 1;
+        const unsigned NAu = (unsigned) __builtin_amdgcn_readfirstlane(F.NA), NAh = NAu >> 1;
+        const bool vec4 = first && cnt >= 4 && (NAh & 3u) == 0;          /* adr0 is a multiple of cnt */
+        GLOBAL_AS const float *src0 = first ? d5 : ipis + (size_t) (slot0 * 2 + 1) * P;
+#else
         GLOBAL_AS const float *src0 = (lv == il + 1) ? d5 + (size_t) (adr0 * 2) * P
                                                      : ipis + (size_t) (slot0 * 2 + 1) * P;
+#endif
         /* the rows of the NEXT state of this lane are requested before the gathers of the
          * current one are waited for (one memory round trip per state instead of two) */
         int s = from + tid;
@@ -800,6 +821,29 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
             constexpr int JG = 4;          /* slots per group: 4 x 2 x (FC_MAXE + 1) gathers in flight per lane (8: -5 %) */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
                 float v[JG][2][FC_MAXE + 1];
+#if FC_D5T
+                if (vec4) {
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int l = 0; l < 2; l++)
+#pragma unroll
+                        for (int i = 0; i <= FC_MAXE; i++) {
+                            const unsigned o = (unsigned) idx[l][i] * NAu + (unsigned) l * NAh + (unsigned) (adr0 + j0);
+                            const f4 q = *(GLOBAL_AS const f4 *) (src0 + o);
+                            v[0][l][i] = q.x; v[1][l][i] = q.y; v[2][l][i] = q.z; v[3][l][i] = q.w;
+                        }
+                } else if (first) {
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++)
+#pragma unroll
+                        for (int l = 0; l < 2; l++)
+#pragma unroll
+                            for (int i = 0; i <= FC_MAXE; i++) {
+                                const int jc = j0 + jj < cnt ? j0 + jj : cnt - 1;
+                                v[jj][l][i] = ldg(src0, (unsigned) idx[l][i] * NAu + (unsigned) l * NAh + (unsigned) (adr0 + jc));
+                            }
+                } else
+#endif
 #pragma unroll
                 for (int jj = 0; jj < JG; jj++)
 #pragma unroll
@@ -851,6 +895,40 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
         /* two addresses per step: packed fp32 multiply and add (v_pk_mul_f32 / v_pk_add_f32,
          * each half rounded like the scalar op; no fused multiply-add), pixels read in pairs */
         typedef float f2 __attribute__((ext_vector_type(2)));
+#if FC_D5T
+        const unsigned NAu = (unsigned) __builtin_amdgcn_readfirstlane(F.NA), NAh = NAu >> 1;
+        int a = 0;
+        if ((NAh & 3u) == 0)
+            /* eight addresses per step: the even and the odd ones are four consecutive floats each */
+            for (; a + 8 <= na; a += 8) {
+                f2 ip[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    f2 vv = { v[k], v[k] };
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        f2 px = { sh.pixels[(a + 2 * u) * 32 + k], sh.pixels[(a + 2 * u) * 32 + 32 + k] };
+                        ip[u] = ip[u] + px * vv;
+                    }
+                }
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 ev = { ip[0].x, ip[1].x, ip[2].x, ip[3].x }, od = { ip[0].y, ip[1].y, ip[2].y, ip[3].y };
+                const unsigned o = (unsigned) s * NAu + ((unsigned) a >> 1);
+                *(GLOBAL_AS f4 *) (D5 + o) = ev;
+                *(GLOBAL_AS f4 *) (D5 + o + NAh) = od;
+            }
+        for (; a < na; a += 2) {
+            f2 ip = { 0.0f, 0.0f };
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                f2 px = { sh.pixels[a * 32 + k], sh.pixels[a * 32 + 32 + k] };
+                f2 vv = { v[k], v[k] };
+                ip = ip + px * vv;
+            }
+            stg(D5, D5_AT(P, NAu, a, s), ip.x);
+            if (a + 1 < na) stg(D5, D5_AT(P, NAu, a + 1, s), ip.y);
+        }
+#else
         for (int a = 0; a < na; a += 2) {
             f2 ip = { 0.0f, 0.0f };
 #pragma unroll
@@ -862,6 +940,7 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
             stg(D5, (unsigned) (a * P + s), ip.x);
             if (a + 1 < na) stg(D5, (unsigned) ((a + 1) * P + s), ip.y);
         }
+#endif
 #if FC_VARIANT_BIG
         if (F.gl0 < F.images_level) {
             float *const D4 = ACT_D4(F, sh);
@@ -1137,7 +1216,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             for (int k = 0; k < 32; k++) vs[k] = ldg((GLOBAL_AS const float *) gimgT, (unsigned) (k * P + s));
 #pragma unroll
             for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * vs[k];
-            stg(gd5, (unsigned) (a * P + s), ip);
+            stg(gd5, D5_AT(P, F.NA, a, s), ip);
         }
     }
 #if FC_VARIANT_BIG

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
+#include <pthread.h>
 #include <utility>
 #include <vector>
 #include "fa_host.h"
@@ -114,6 +115,54 @@ static bool needs_wide_variant(const fa_cparams *cp)
     return depths - 1 > FC_MAXDEPTH_NARROW
            || (depths + cp->lc_max_level - cp->lc_min_level) * n16 > FC_SNAP16_NARROW
            || depths * 4 * ((2 * cp->limit_level + 3) / 4) > FC_SNAPTM_NARROW;
+}
+
+/* Capacity memory.  The first guess of a frame's state capacity (fa_core_stage) is a formula of the frame size;
+ * a frame that needs more is searched again with 1.5 x the capacity -- and so would be every later frame of the
+ * same kind: the P frames of a 720p colour sequence with --prediction need 1.5 x what their I frames need, and
+ * each was searched twice (BASELINE config 5: 20 launches for 10 frames).  So the process remembers, per kind of
+ * frame (size, colour, frame type class, block levels, price), the largest need it has seen, and the guess starts
+ * there.  The capacity is memory layout only: streams do not depend on it. */
+struct CapHint { unsigned long long key; int needP, needPA; };
+static pthread_mutex_t g_hint_mu = PTHREAD_MUTEX_INITIALIZER;
+static CapHint g_hints[64];
+static unsigned g_hint_n, g_hint_next;
+static unsigned long long cap_key(const fa_job *job)
+{
+    const fa_cparams *cp = &job->cp;
+    unsigned pb;
+    memcpy(&pb, &cp->price, 4);
+    const unsigned v[] = { job->image->width, job->image->height, (unsigned) (job->image->color != 0),
+                           (unsigned) (job->frame_type != FA_I_FRAME), (unsigned) (cp->prediction != 0), cp->lc_min_level,
+                           cp->lc_max_level, cp->p_min_level, cp->p_max_level, cp->max_elements, pb, cp->limit_states };
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof v / sizeof v[0]; i++)
+        for (int b = 0; b < 4; b++) { h ^= (v[i] >> (8 * b)) & 0xff; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+static void cap_hint_get(const fa_job *job, int *needP, int *needPA)
+{
+    const unsigned long long k = cap_key(job);
+    *needP = *needPA = 0;
+    pthread_mutex_lock(&g_hint_mu);
+    for (unsigned i = 0; i < g_hint_n; i++)
+        if (g_hints[i].key == k) { *needP = g_hints[i].needP; *needPA = g_hints[i].needPA; break; }
+    pthread_mutex_unlock(&g_hint_mu);
+}
+static void cap_hint_put(const fa_job *job, int needP, int needPA)
+{
+    const unsigned long long k = cap_key(job);
+    pthread_mutex_lock(&g_hint_mu);
+    unsigned i = 0;
+    for (; i < g_hint_n; i++) if (g_hints[i].key == k) break;
+    if (i == g_hint_n) {
+        if (g_hint_n < sizeof g_hints / sizeof g_hints[0]) g_hint_n++;
+        else i = g_hint_next++ % (sizeof g_hints / sizeof g_hints[0]);       /* full: round robin */
+        g_hints[i].key = k; g_hints[i].needP = g_hints[i].needPA = 0;
+    }
+    if (needP > g_hints[i].needP) g_hints[i].needP = needP;
+    if (needPA > g_hints[i].needPA) g_hints[i].needPA = needPA;
+    pthread_mutex_unlock(&g_hint_mu);
 }
 
 /* (fiasco_amd_get_stats / _reset_stats: with the multi-device entries, end of file) */
@@ -598,6 +647,7 @@ struct FrameSlot {
     char    *base = nullptr;
     size_t   bytes = 0;
     int      P = 0, PA = 0;
+    int      floorP = 0, floorPA = 0;   /* what frames of this kind needed before (capacity memory) */
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
@@ -1099,10 +1149,18 @@ static void *core1_stage(unsigned n, fa_job *jobs)
         unsigned bw = fa_width_of_level(cp->lc_max_level), bh = fa_height_of_level(cp->lc_max_level);
         size_t blocks = (size_t) ((jobs[i].image->width + bw - 1) / bw) * ((jobs[i].image->height + bh - 1) / bh);
         size_t guess = blocks + blocks * 3 / 8 + 64;
+        /* predicted frames: the residual of a predicted block subdivides where the block itself would not --
+         * 720p colour P frames with --prediction end with 2.0 .. 2.3 table states per block (config 5) */
+        if (jobs[i].frame_type != FA_I_FRAME) guess = blocks * 5 / 2 + 64;
         /* tests / experiments: FIASCO_AMD_CAP_GUESS=<states> forces the first guess (a frame that
          * outgrows it is encoded again with 1.5 x the capacity, complete_wave) */
         if (fa_knob("FIASCO_AMD_CAP_GUESS") && atoi(fa_knob("FIASCO_AMD_CAP_GUESS")) > 0)
             guess = (size_t) atoi(fa_knob("FIASCO_AMD_CAP_GUESS"));
+        /* what frames of this kind needed before (cap_hint_put): 1/16 on top, frames of a sequence drift */
+        int hintP = 0, hintPA = 0;
+        const bool forced = fa_knob("FIASCO_AMD_CAP_GUESS") && atoi(fa_knob("FIASCO_AMD_CAP_GUESS")) > 0;
+        if (!forced && !fa_knob("FIASCO_AMD_NO_CAP_HINT")) cap_hint_get(&jobs[i], &hintP, &hintPA);
+        if ((size_t) hintP + hintP / 16 + 32 > guess) guess = (size_t) hintP + hintP / 16 + 32;
         if (guess > cp->limit_states) guess = cp->limit_states;
         FrameSlot fs;
         fs.job = (int) i;
@@ -1122,7 +1180,12 @@ static void *core1_stage(unsigned n, fa_job *jobs)
         /* colour: the two chroma bands add auxiliary states (no tables) */
         size_t cap = align_up(cp->limit_states, 64);
         fs.PA = jobs[i].image->color ? (int) (3 * (size_t) fs.P > cap ? cap : 3 * (size_t) fs.P) : fs.P;
+        if ((size_t) hintPA + hintPA / 16 + 32 > (size_t) fs.PA) {
+            const size_t want = align_up((size_t) hintPA + hintPA / 16 + 32, 64);
+            fs.PA = (int) (want > cap ? cap : want);
+        }
         if (fs.PA < fs.P) fs.PA = fs.P;
+        if (hintP) { fs.floorP = hintP + hintP / 16 + 32; fs.floorPA = hintPA + hintPA / 16 + 32; }
         S->slots.push_back(fs);
     }
     /* Stage the frames.  Every frame gets a slab of its own until the device is full -- as many
@@ -1179,11 +1242,13 @@ static void *core1_stage(unsigned n, fa_job *jobs)
                 unsigned bw = fa_width_of_level(cp->lc_max_level), bh = fa_height_of_level(cp->lc_max_level);
                 size_t blocks = (size_t) ((job->image->width + bw - 1) / bw) * ((job->image->height + bh - 1) / bh);
                 size_t tight = align_up(blocks + blocks * 3 / 20 + 64, 64);
+                if ((size_t) fs.floorP > tight) tight = align_up((size_t) fs.floorP, 64);   /* never below a known need */
                 if (tight > cp->limit_states) tight = align_up(cp->limit_states, 64);
                 if ((size_t) fs.P <= tight || fs.spec) continue;
                 const size_t cap = align_up(cp->limit_states, 64);
                 fs.P = (int) tight;
                 fs.PA = job->image->color ? (int) (3 * tight > cap ? cap : 3 * tight) : fs.P;
+                if ((size_t) fs.floorPA > (size_t) fs.PA) fs.PA = (int) (align_up((size_t) fs.floorPA, 64) > cap ? cap : align_up((size_t) fs.floorPA, 64));
                 if (fs.PA < fs.P) fs.PA = fs.P;
             }
     }
@@ -1399,6 +1464,10 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     for (int k = 0; k < 8; k++) g_stats.dbg[k] += F.dbg[k];
     g_stats.states_sum += ns;
     if (ns > g_stats.states_max) g_stats.states_max = ns;
+    cap_hint_put(job, F.ystates_out, F.states);
+    if (fa_knob("FIASCO_AMD_CAP_TRACE"))
+        fprintf(stderr, "capacity: frame type %d used %d table states of %d, %d states of %d\n", job->frame_type, F.ystates_out,
+                fs.P, F.states, fs.PA);
     return 1;
 }
 

@@ -139,6 +139,7 @@ typedef struct DevFrame {
     /* ---- results ---- */
     int      status;
     int      states, root_state;
+    int      ystates_out;  /* states that own tables (gray / Y band) at the end: the host's capacity memory */
     float    costs, err, tree_bits, matrix_bits, weights_bits;      /* band 0 (gray / Y) */
     float    c_costs[2], c_err[2], c_tree_bits[2], c_matrix_bits[2], c_weights_bits[2];  /* Cb, Cr */
     int      lc_min_out;   /* min block level after the frame (codec/coder.c:785-797 ratchet) */

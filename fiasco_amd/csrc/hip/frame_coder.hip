@@ -3654,6 +3654,11 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         F.n_mp = sh.cnt.n_mp; F.n_steps = sh.cnt.n_steps; F.n_blocks = sh.cnt.n_blocks;
         F.n_appends = sh.cnt.n_appends; F.n_fulleval = sh.cnt.n_fulleval;
         F.n_blockevals = sh.cnt.n_blockevals; F.t_mpA = sh.cnt.t_mpA; F.t_mpB = sh.cnt.t_mpB;
+#if FC_VARIANT_BIG && !defined(FC_SERIAL_PROFILE) && !defined(FC_PM)
+        /* the ops only this build has (ticks): chroma set-up, prediction set-up / finish, norms, motion search */
+        F.dbg[2] = tk[OP_CHROMA]; F.dbg[3] = tk[OP_PRED_SETUP]; F.dbg[4] = tk[OP_PRED_FINISH];
+        F.dbg[5] = tk[OP_NORMS]; F.dbg[6] = tk[OP_MC_SEARCH];
+#endif
 #ifdef FC_SERIAL_PROFILE
         for (int k = 0; k < 8; k++) F.dbg[k] = sh.tk_ph[k];
         F.dbg[0] = sh.tk_init[0]; F.dbg[7] = sh.tk_init[1];      /* d5 / ipis of init_range */
@@ -3678,6 +3683,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */
         F.states = sh.states;
+        F.ystates_out = sh.band ? sh.ystates : sh.states;
         F.lc_min_out = sh.lc_min;
         F.status = sh.failed ? sh.failed : FC_OK;
 #if FC_SPEC

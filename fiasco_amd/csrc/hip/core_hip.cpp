@@ -1035,18 +1035,28 @@ static int stage_slot(Staged *S, FrameSlot &fs)
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
             return 0;
         }
+    /* reference frames the device decoder left on this device (fa_image.dev, frame_decoder.inc) are taken from
+     * there; anything else comes from the host planes */
+    int here = -1;
+    if (hipGetDevice(&here) != hipSuccess) { (void) hipGetLastError(); here = -1; }
     if (job->frame_type != FA_I_FRAME && job->past)
         for (int b = 0; b < bands; b++)
-            if (hipMemcpyAsync(fs.base + fs.L.past + (size_t) b * npix * 2, job->past->pixels[b], npix * 2,
-                               hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            if ((job->past->dev && job->past->dev_id == here
+                 ? hipMemcpyAsync(fs.base + fs.L.past + (size_t) b * npix * 2, (const int16_t *) job->past->dev + (size_t) b * npix, npix * 2,
+                                  hipMemcpyDeviceToDevice, S->stream)
+                 : hipMemcpyAsync(fs.base + fs.L.past + (size_t) b * npix * 2, job->past->pixels[b], npix * 2,
+                                  hipMemcpyHostToDevice, S->stream)) != hipSuccess) {
                 snprintf(job->errmsg, sizeof job->errmsg, "HIP error: reference frame upload failed");
                 slab_release(fs.base, fs.bytes); fs.base = nullptr;
                 return 0;
             }
     if (job->frame_type == FA_B_FRAME && job->future)
         for (int b = 0; b < bands; b++)
-            if (hipMemcpyAsync(fs.base + fs.L.future + (size_t) b * npix * 2, job->future->pixels[b], npix * 2,
-                               hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            if ((job->future->dev && job->future->dev_id == here
+                 ? hipMemcpyAsync(fs.base + fs.L.future + (size_t) b * npix * 2, (const int16_t *) job->future->dev + (size_t) b * npix, npix * 2,
+                                  hipMemcpyDeviceToDevice, S->stream)
+                 : hipMemcpyAsync(fs.base + fs.L.future + (size_t) b * npix * 2, job->future->pixels[b], npix * 2,
+                                  hipMemcpyHostToDevice, S->stream)) != hipSuccess) {
                 snprintf(job->errmsg, sizeof job->errmsg, "HIP error: reference frame upload failed");
                 slab_release(fs.base, fs.bytes); fs.base = nullptr;
                 return 0;
@@ -2248,3 +2258,5 @@ extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)
     fa_core_unstage(h);
     return good;
 }
+
+#include "frame_decoder.inc"

@@ -362,6 +362,20 @@ int fiasco_amd_batch_stats(const fiasco_amd_batch_t *b, unsigned i, unsigned ban
  * w x w -- fiasco_image_get_height() returns the width, lib/image.c:134 -- so its mean is ours x h / w for
  * h <= w (the tests convert); here the mean is over the pixels of the image.  For colour frames the three
  * planes Y, Cb, Cr are compared as they are, without pnmpsnr's detour through RGB. */
+/* the frame of a finished intra job through the core's decoder (the device; the host decoder in the test oracle) */
+static fa_image *decode_job(const fa_job *job)
+{
+    fa_dec_job d;
+    memset(&d, 0, sizeof d);
+    d.wfa = job->wfa; d.width = job->image->width; d.height = job->image->height; d.color = job->image->color;
+    d.frame_type = FA_I_FRAME;
+    if (fa_core_decode_frames(1, &d) != 1 || !d.out) {
+        fa_set_error("%s", d.errmsg[0] ? d.errmsg : "decoder failed");
+        return NULL;
+    }
+    return d.out;
+}
+
 int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double psnr_db[3], double mse[3])
 {
     const fa_image *orig;
@@ -376,7 +390,7 @@ int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double
         return 0;
     }
     orig = b->jobs[i].image;
-    dec = fa_decode_image(orig->width, orig->height, b->jobs[i].wfa, orig->color);
+    dec = decode_job(&b->jobs[i]);
     if (!dec) return 0;
     nb = orig->color ? 3 : 1;
     for (band = 0; band < 3; band++) { if (psnr_db) psnr_db[band] = 0; if (mse) mse[band] = 0; }
@@ -416,7 +430,7 @@ int fiasco_amd_batch_decode_plane(const fiasco_amd_batch_t *b, unsigned i, unsig
         fa_set_error("fiasco_amd_batch_decode_plane: intra frames only, band < %u", orig->color ? 3u : 1u);
         return 0;
     }
-    dec = fa_decode_image(orig->width, orig->height, b->jobs[i].wfa, orig->color);
+    dec = decode_job(&b->jobs[i]);
     if (!dec) return 0;
     n = (size_t) orig->width * orig->height;
     for (k = 0; k < n; k++) {

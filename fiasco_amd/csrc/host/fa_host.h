@@ -94,6 +94,9 @@ typedef struct fa_image {
     int      color;
     int16_t *pixels[3];
     int      borrowed;       /* planes belong to somebody else (upload staging buffer) */
+    void    *dev;            /* decoded frames: the same planes [bands][height][width] on device dev_id, or NULL
+                                (fa_core_decode_frames; released by fa_image_free through fa_core_release_dev) */
+    int      dev_id;
 } fa_image;
 /* parse raw P5/P6 from memory; returns NULL + error message on failure */
 fa_image *fa_image_from_pnm(const unsigned char *buf, size_t len, const char *name);
@@ -149,6 +152,21 @@ void      fa_extract_mc_block(int16_t *mcblock, unsigned width, unsigned height,
                               const int16_t *reference, unsigned ref_width,
                               unsigned xo, unsigned yo, int mx, int my);
 double    fa_plane_mse(const int16_t *a, const int16_t *b, size_t n);
+
+/* the decoder as the core runs it (device library: csrc/hip/frame_decoder.inc; test oracle: the host decoder
+ * above): decode_image for every job, restore_mc for the P/B frames among them (codec/coder.c:647-651) */
+typedef struct fa_dec_job {
+    const fa_wfa   *wfa;                  /* in  */
+    unsigned        width, height;        /* in: the coded size (the decoder crops to it) */
+    int             color, frame_type;    /* in  */
+    const fa_image *past, *future;        /* in: references of a P/B frame */
+    unsigned        p_max_level;          /* in  */
+    int             skip;                 /* in: leave this job alone (keeps the index -> device dealing) */
+    fa_image       *out;                  /* out: the frame, or NULL + errmsg */
+    char            errmsg[160];
+} fa_dec_job;
+int  fa_core_decode_frames(unsigned n, fa_dec_job *jobs);    /* number of frames decoded */
+void fa_core_release_dev(void *dev, int dev_id);
 
 /* ---------------- stream info (reference codec/wfa.h:65-110 wfa_info_t) ----------- */
 typedef struct fa_info {

@@ -73,6 +73,7 @@ void fa_image_free(fa_image *im)
 {
     int b;
     if (!im) return;
+    if (im->dev) fa_core_release_dev(im->dev, im->dev_id);
     if (!im->borrowed)
         for (b = 0; b < 3; b++) free(im->pixels[b]);
     free(im);

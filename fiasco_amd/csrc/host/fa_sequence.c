@@ -26,9 +26,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <math.h>
-#include <pthread.h>
 #include <time.h>
-#include <unistd.h>
 #include "fa_host.h"
 
 /* developer aid: FIASCO_AMD_SEQ_TIMING=1 prints where a sweep spends its time (stderr) */
@@ -200,35 +198,6 @@ typedef struct gop_run {
     unsigned carry;
 } gop_run;
 
-/* decoding the references of one step: share `first, first + stride, ...' of the batch */
-#define DEC_THREADS 16
-typedef struct dec_share {
-    fa_seq *s;
-    gop_run *run;
-    const unsigned *who;
-    const uint8_t *need;
-    unsigned step, nb, first, stride;
-} dec_share;
-static void *dec_thread(void *arg)
-{
-    dec_share *d = (dec_share *) arg;
-    fa_seq *s = d->s;
-    unsigned b;
-    for (b = d->first; b < d->nb; b += d->stride) {
-        gop_run *q = &d->run[d->who[b]];
-        const unsigned k = s->gfirst[q->g] + d->step;
-        if (!d->need[b]) continue;
-        q->reconst = fa_decode_image(s->wi.width, s->wi.height, s->wfa[k], s->color);
-        if (!q->reconst || (s->type[k] != FA_I_FRAME
-                            && !fa_restore_mc(q->reconst, q->past, q->future, s->wfa[k], s->wi.p_max_level))) {
-            /* (the message is this thread's; the slot is the GOP's own) */
-            snprintf(s->gerr[q->g], 160, "%s", fiasco_get_error_message());
-            s->gfail[q->g] = 1; q->dead = 1;
-        }
-    }
-    return NULL;
-}
-
 /* Partition search of the GOPs of this rank marked in todo[], each starting from carry_in[g].
  * Frame j of all of them is one batch for the core.  Returns 0 only on an internal error (out of
  * memory); a GOP whose search fails is recorded (fa_seq_gop_result) -- whether that is an error
@@ -241,10 +210,11 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     fa_image **ims = (fa_image **) calloc(s->ngop ? s->ngop : 1, sizeof *ims);
     unsigned *who = (unsigned *) calloc(s->ngop ? s->ngop : 1, sizeof *who);
     uint8_t *need = (uint8_t *) calloc(s->ngop ? s->ngop : 1, 1);
+    fa_dec_job *djobs = (fa_dec_job *) calloc(s->ngop ? s->ngop : 1, sizeof *djobs);
     unsigned nrun = 0, g, r, step, maxlen = 0;
     int rc = 0;
     double t_prep = 0, t_core = 0, t_dec = 0, t0;
-    if (!run || !jobs || !ims || !who || !need) { fa_set_error("Out of memory!"); goto out; }
+    if (!run || !jobs || !ims || !who || !need || !djobs) { fa_set_error("Out of memory!"); goto out; }
     for (g = 0; g < s->ngop; g++) {
         unsigned k;
         if (!fa_seq_is_mine(s, g) || !todo[g]) continue;
@@ -330,23 +300,30 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             }
             fa_image_free(ims[b]); ims[b] = NULL;
         }
-        /* the references: one decode per GOP, independent of each other -- side by side on the host's cores */
+        /* the references of the frames to come (codec/coder.c:647-651): decode_image + restore_mc, one batch for
+         * the core -- the device, which keeps the planes for the next search (fa_image.dev) */
         {
-            dec_share sh[DEC_THREADS];
-            pthread_t th[DEC_THREADS];
-            int started[DEC_THREADS] = { 0 };
-            long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-            unsigned nt = ncpu > DEC_THREADS ? DEC_THREADS : ncpu < 1 ? 1 : (unsigned) ncpu, t;
-            if (nt > nb) nt = nb;
-            for (t = 0; t < nt; t++) {
-                sh[t].s = s; sh[t].run = run; sh[t].who = who; sh[t].need = need;
-                sh[t].step = step; sh[t].nb = nb; sh[t].first = t; sh[t].stride = nt;
+            unsigned any = 0;
+            for (b = 0; b < nb; b++) {
+                gop_run *q = &run[who[b]];
+                const unsigned k = s->gfirst[q->g] + step;
+                memset(&djobs[b], 0, sizeof djobs[b]);
+                djobs[b].skip = !need[b];
+                if (!need[b]) continue;
+                any = 1;
+                djobs[b].wfa = s->wfa[k]; djobs[b].width = s->wi.width; djobs[b].height = s->wi.height;
+                djobs[b].color = s->color; djobs[b].frame_type = s->type[k];
+                djobs[b].past = q->past; djobs[b].future = q->future; djobs[b].p_max_level = s->wi.p_max_level;
             }
-            for (t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, dec_thread, &sh[t]) == 0;
-            dec_thread(&sh[0]);
-            for (t = 1; t < nt; t++) {
-                if (started[t]) pthread_join(th[t], NULL);
-                else dec_thread(&sh[t]);
+            if (any) (void) fa_core_decode_frames(nb, djobs);
+            for (b = 0; b < nb; b++) {
+                gop_run *q = &run[who[b]];
+                if (!need[b]) continue;
+                q->reconst = djobs[b].out;
+                if (!q->reconst) {
+                    snprintf(s->gerr[q->g], 160, "%s", djobs[b].errmsg[0] ? djobs[b].errmsg : "decoder failed");
+                    s->gfail[q->g] = 1; q->dead = 1;
+                }
             }
         }
         t_dec += seq_now() - t0;
@@ -361,7 +338,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     rc = 1;
 out:
     for (r = 0; run && r < nrun; r++) { fa_image_free(run[r].reconst); fa_image_free(run[r].past); fa_image_free(run[r].future); }
-    free(run); free(jobs); free(ims); free(who); free(need);
+    free(run); free(jobs); free(ims); free(who); free(need); free(djobs);
     return rc;
 }
 

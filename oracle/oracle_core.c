@@ -1869,6 +1869,26 @@ int fa_core_encode_frames(unsigned n, fa_job *jobs)
 
 const char *fa_core_name(void) { return "oracle-cpu"; }
 
+/* the decoder of the oracle build: the host restatement of codec/decoder.c / codec/motion.c (fa_decoder.c) */
+int fa_core_decode_frames(unsigned n, fa_dec_job *jobs)
+{
+    unsigned i;
+    int good = 0;
+    for (i = 0; i < n; i++) {
+        fa_dec_job *j = &jobs[i];
+        j->out = NULL; j->errmsg[0] = 0;
+        if (j->skip) continue;
+        j->out = fa_decode_image(j->width, j->height, j->wfa, j->color);
+        if (j->out && j->frame_type != FA_I_FRAME && !fa_restore_mc(j->out, j->past, j->future, j->wfa, j->p_max_level)) {
+            fa_image_free(j->out); j->out = NULL;
+        }
+        if (!j->out) snprintf(j->errmsg, sizeof j->errmsg, "%s", fiasco_get_error_message());
+        else good++;
+    }
+    return good;
+}
+void fa_core_release_dev(void *dev, int dev_id) { (void) dev; (void) dev_id; }
+
 /* staged form of the seam: the CPU oracle has nothing to make resident.  To behave like a
  * device that works while the host goes on, a submitted pass remembers WHICH frames it was
  * submitted with (the host may hand over the next ones before it collects, fa_core_upload_*)

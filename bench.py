@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie-loop", action="store_true", help="skip the PCIe-inclusive timed loop")
     ap.add_argument("--no-small-launches", action="store_true", help="skip the single-frame / 16-frame timings")
+    ap.add_argument("--no-decoder", action="store_true", help="skip the decoder pass over the frames (SURVEY 8f row F4)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank encodes --frames-per-gpu frames (default); strong: --frames-per-gpu is the "
                          "TOTAL of the job, dealt round robin to the ranks (BASELINE config 4: --scaling strong "
@@ -381,10 +382,30 @@ def main():
         dt = time.perf_counter() - t0
         st = lib.get_stats()
         root = batch.stats(0)          # coder-side error of the survey frame
+        decoder = None
         try:                           # ... and its decoded PSNR (dfiasco -s 0 + pnmpsnr)
             decoded_psnr = batch.decode_psnr(0)[0][0] if rank == 0 else None
-        except Exception:
+            if rank == 0 and not a.no_decoder:
+                # all frames of the pass through the device decoder (one launch per level and
+                # frame, csrc/hip/frame_decoder.inc) + download + the host's pnmpsnr sum -- outside the timed region
+                lib.reset_stats()
+                t_dec = time.time()
+                good, ps, _ = batch.decode_psnr_all()
+                t_dec = time.time() - t_dec
+                dst = lib.get_stats()
+                decoder = {"workload": "decode_image of the %d automata of one pass + PSNR against the inputs" % len(ps),
+                           "frames": good, "seconds": round(t_dec, 3), "frames_per_s": round(good / t_dec, 1) if t_dec > 0 else None,
+                           "psnr_db_min_max": [round(min(p[0] for p in ps), 2), round(max(p[0] for p in ps), 2)],
+                           # device side alone (HIP events around the flights: automaton upload + one kernel per level +
+                           # assembly): algorithmic bytes = 2 per level-image pixel written and per (pixel, term) read
+                           "device_seconds": round(dst.decoder_us / 1e6, 4),
+                           "device_frames_per_s": round(dst.decoder_frames / (dst.decoder_us / 1e6), 1) if dst.decoder_us else None,
+                           "device_GBps": round(dst.decoder_bytes / (dst.decoder_us / 1e6) / 1e9, 1) if dst.decoder_us else None,
+                           "device_frac_of_hbm_peak": round(dst.decoder_bytes / (dst.decoder_us / 1e6) / 8e12, 4) if dst.decoder_us else None,
+                           "frame0_equals_single_call": abs(ps[0][0] - decoded_psnr) < 1e-12}
+        except Exception as e:
             decoded_psnr = None
+            decoder = {"error": str(e)[:200]}
         assert out is not None and all(o is not None for o in out), lib.error_message()
         # ---- loop B: the frames of every pass cross PCIe inside the timed region ----
         if not a.no_pcie_loop:
@@ -473,6 +494,7 @@ def main():
                        # decoded like `dfiasco -s 0`, compared like bin/pnmpsnr.c (reference tools on the
                        # reference's stream of the survey frame: 34.02 dB, tests/golden/MANIFEST.json)
                        "decoded_psnr_db": decoded_psnr if not dry else None,
+                       "decoder": decoder if not dry else None,
                        # what `value` times and what it does not: the reference's own timer (codec/coder.c:709,884)
                        # also covers reading the PNM file and writing the .fco file
                        "value_covers": "device search + automaton download + host .fco entropy writer into memory, "

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fa_core_name", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_batch_decode_plane", "fiasco_amd_c_options_set_models",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_batch_decode_psnr_all", "fiasco_amd_batch_decode_plane", "fiasco_amd_c_options_set_models",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload", "fiasco_amd_set_devices", "fiasco_amd_device_count",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
@@ -66,7 +66,9 @@ class Stats(ctypes.Structure):
                 ("spec_confirmed", ctypes.c_ulonglong), ("spec_wrong", ctypes.c_ulonglong),
                 ("spec_timeout", ctypes.c_ulonglong), ("spec_inline", ctypes.c_ulonglong),
                 ("spec_wait", ctypes.c_ulonglong), ("spec_tab_used", ctypes.c_ulonglong),
-                ("spec_tab_missed", ctypes.c_ulonglong), ("spec_adopted", ctypes.c_ulonglong)]
+                ("spec_tab_missed", ctypes.c_ulonglong), ("spec_adopted", ctypes.c_ulonglong),
+                ("decoder_frames", ctypes.c_ulonglong), ("decoder_bytes", ctypes.c_ulonglong),
+                ("decoder_us", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):
@@ -310,6 +312,17 @@ class Batch:
         if not f(self.handle, i, band, buf):
             raise FiascoError(self.lib.error_message())
         return buf.raw
+
+    def decode_psnr_all(self):
+        """fiasco_amd_batch_decode_psnr_all: (n decoded, [[psnr dB per band]], [[mse per band]]) of all frames,
+        decoded by one call of the device decoder."""
+        f = self.lib.L.fiasco_amd_batch_decode_psnr_all
+        n = self.n
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        f.restype = ctypes.c_int
+        p = (ctypes.c_double * (3 * n))(); m = (ctypes.c_double * (3 * n))()
+        good = f(self.handle, p, m)
+        return good, [list(p[3 * i:3 * i + 3]) for i in range(n)], [list(m[3 * i:3 * i + 3]) for i in range(n)]
 
     def decode_psnr(self, i):
         """fiasco_amd_batch_decode_psnr: decoded PSNR in dB per band of frame i (what `dfiasco -s 0` +

@@ -376,23 +376,11 @@ static fa_image *decode_job(const fa_job *job)
     return d.out;
 }
 
-int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double psnr_db[3], double mse[3])
+/* mean squared error and PSNR of a decoded frame against its original, as bin/pnmpsnr.c:92-101 sums them */
+static void psnr_of(const fa_image *orig, const fa_image *dec, double psnr_db[3], double mse[3])
 {
-    const fa_image *orig;
-    fa_image *dec;
-    unsigned band, nb;
-    if (!b || i >= b->n || !b->jobs[i].status || !b->jobs[i].wfa) {
-        fa_set_error("fiasco_amd_batch_decode_psnr: frame %u has no finished automaton", i);
-        return 0;
-    }
-    if (b->jobs[i].frame_type != FA_I_FRAME) {
-        fa_set_error("fiasco_amd_batch_decode_psnr: intra frames only (a P/B frame needs its reference frames)");
-        return 0;
-    }
-    orig = b->jobs[i].image;
-    dec = decode_job(&b->jobs[i]);
-    if (!dec) return 0;
-    nb = orig->color ? 3 : 1;
+    const unsigned nb = orig->color ? 3 : 1;
+    unsigned band;
     for (band = 0; band < 3; band++) { if (psnr_db) psnr_db[band] = 0; if (mse) mse[band] = 0; }
     for (band = 0; band < nb; band++) {
         const int16_t *p = orig->pixels[band], *q = dec->pixels[band];
@@ -409,8 +397,73 @@ int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double
         if (mse) mse[band] = norm;
         if (psnr_db) psnr_db[band] = norm > 1e-4 ? 10 * log(255.0 * 255.0 / norm) / log(10.0) : INFINITY;
     }
+}
+
+int fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *b, unsigned i, double psnr_db[3], double mse[3])
+{
+    fa_image *dec;
+    if (!b || i >= b->n || !b->jobs[i].status || !b->jobs[i].wfa) {
+        fa_set_error("fiasco_amd_batch_decode_psnr: frame %u has no finished automaton", i);
+        return 0;
+    }
+    if (b->jobs[i].frame_type != FA_I_FRAME) {
+        fa_set_error("fiasco_amd_batch_decode_psnr: intra frames only (a P/B frame needs its reference frames)");
+        return 0;
+    }
+    dec = decode_job(&b->jobs[i]);
+    if (!dec) return 0;
+    psnr_of(b->jobs[i].image, dec, psnr_db, mse);
     fa_image_free(dec);
     return 1;
+}
+
+/* All frames of the batch in ONE call of the core's decoder (the device runs them back to back on a stream, every
+ * device of the process its share); psnr_db / mse: [n][3], either may be NULL.  Frames without a finished intra
+ * automaton get zeros.  Returns the number of frames decoded. */
+static void *psnr_thread(void *arg);
+typedef struct psnr_share { const fiasco_amd_batch_t *b; fa_dec_job *d; double *psnr_db, *mse; unsigned first, stride; } psnr_share;
+int fiasco_amd_batch_decode_psnr_all(const fiasco_amd_batch_t *b, double *psnr_db, double *mse)
+{
+    enum { MAXT = 16 };
+    fa_dec_job *d;
+    psnr_share sh[MAXT];
+    pthread_t th[MAXT];
+    int started[MAXT] = { 0 }, good;
+    unsigned i, nt, t;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (!b || !b->n) { fa_set_error("fiasco_amd_batch_decode_psnr_all: empty batch"); return 0; }
+    d = (fa_dec_job *) calloc(b->n, sizeof *d);
+    if (!d) { fa_set_error("Out of memory!"); return 0; }
+    for (i = 0; i < b->n; i++) {
+        const fa_job *job = &b->jobs[i];
+        if (!job->status || !job->wfa || job->frame_type != FA_I_FRAME) { d[i].skip = 1; continue; }
+        d[i].wfa = job->wfa; d[i].width = job->image->width; d[i].height = job->image->height; d[i].color = job->image->color;
+        d[i].frame_type = FA_I_FRAME;
+    }
+    good = fa_core_decode_frames(b->n, d);
+    nt = ncpu > MAXT ? MAXT : ncpu < 1 ? 1 : (unsigned) ncpu;
+    if (nt > b->n) nt = b->n;
+    for (t = 0; t < nt; t++) { sh[t].b = b; sh[t].d = d; sh[t].psnr_db = psnr_db; sh[t].mse = mse; sh[t].first = t; sh[t].stride = nt; }
+    for (t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, psnr_thread, &sh[t]) == 0;
+    psnr_thread(&sh[0]);
+    for (t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else psnr_thread(&sh[t]); }
+    for (i = 0; i < b->n; i++) {
+        if (!d[i].skip && !d[i].out && d[i].errmsg[0]) fa_set_error("%s", d[i].errmsg);
+        fa_image_free(d[i].out);
+    }
+    free(d);
+    return good;
+}
+static void *psnr_thread(void *arg)
+{
+    psnr_share *s = (psnr_share *) arg;
+    unsigned i, k;
+    for (i = s->first; i < s->b->n; i += s->stride) {
+        double p[3] = { 0, 0, 0 }, m[3] = { 0, 0, 0 };
+        if (s->d[i].out) psnr_of(s->b->jobs[i].image, s->d[i].out, p, m);
+        for (k = 0; k < 3; k++) { if (s->psnr_db) s->psnr_db[i * 3 + k] = p[k]; if (s->mse) s->mse[i * 3 + k] = m[k]; }
+    }
+    return NULL;
 }
 
 /* The decoded frame itself: band `band` of frame i as bytes, clip((pixel >> 4) + 128) in raster order

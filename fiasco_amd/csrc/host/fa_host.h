@@ -162,6 +162,7 @@ typedef struct fa_dec_job {
     const fa_image *past, *future;        /* in: references of a P/B frame */
     unsigned        p_max_level;          /* in  */
     int             skip;                 /* in: leave this job alone (keeps the index -> device dealing) */
+    int             keep_dev;             /* in: leave the planes on the device too (out->dev): reference frames */
     fa_image       *out;                  /* out: the frame, or NULL + errmsg */
     char            errmsg[160];
 } fa_dec_job;

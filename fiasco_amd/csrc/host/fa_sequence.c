@@ -308,7 +308,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
                 gop_run *q = &run[who[b]];
                 const unsigned k = s->gfirst[q->g] + step;
                 memset(&djobs[b], 0, sizeof djobs[b]);
-                djobs[b].skip = !need[b];
+                djobs[b].skip = !need[b]; djobs[b].keep_dev = 1;
                 if (!need[b]) continue;
                 any = 1;
                 djobs[b].wfa = s->wfa[k]; djobs[b].width = s->wi.width; djobs[b].height = s->wi.height;

@@ -159,6 +159,10 @@ int  fiasco_amd_batch_stats(const fiasco_amd_batch_t *batch, unsigned i, unsigne
  * smoothing and compared with the input as bytes.  psnr_db / mse: one entry per band (gray: [0] only; may
  * be NULL).  Intra frames only.  1 ok / 0 + error message. */
 int  fiasco_amd_batch_decode_psnr(const fiasco_amd_batch_t *batch, unsigned i, double psnr_db[3], double mse[3]);
+/* ... of every frame of the batch, decoded by ONE call of the device decoder (csrc/hip/
+ * frame_decoder.inc replaces decode_image, codec/decoder.c:411-536): psnr_db / mse are [n][3] (either may be NULL),
+ * zeros for frames without a finished intra automaton.  Returns the number of frames decoded. */
+int  fiasco_amd_batch_decode_psnr_all(const fiasco_amd_batch_t *batch, double *psnr_db, double *mse);
 /* ... and the decoded frame itself: one band as width x height bytes, clip((pixel >> 4) + 128) -- for a gray frame
  * the payload of the PGM `dfiasco -s 0 -o` writes (lib/image.c:449-483). */
 int  fiasco_amd_batch_decode_plane(const fiasco_amd_batch_t *batch, unsigned i, unsigned band, unsigned char *out);

@@ -45,6 +45,10 @@ typedef struct fiasco_amd_stats {
     unsigned long long spec_tab_used, spec_tab_missed;
     /* wrong guesses after which the chain took over the verifier's state instead of searching the block again */
     unsigned long long spec_adopted;
+    /* the device decoder (csrc/hip/frame_decoder.inc): frames decoded, their algorithmic bytes
+     * (2 bytes per pixel of every level image written and per (pixel, term) read, + the frame), device time of
+     * the flights in microseconds (HIP events around uploads + kernels of a flight of <= 32 frames) */
+    unsigned long long decoder_frames, decoder_bytes, decoder_us;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);

@@ -830,6 +830,16 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.price = cp->price;
     F.lc_min = (int) cp->lc_min_level; F.lc_max = (int) cp->lc_max_level;
     F.images_level = (int) cp->images_level; F.max_elements = (int) cp->max_elements;
+    {
+        unsigned live = cp->max_elements;
+        for (unsigned st = 0; st < w->basis_states; st++)
+            for (unsigned l = 0; l < 2; l++) {
+                unsigned e = 0;
+                while (e < 6 && FA_INTO(w, st, l, e) != FA_NO_EDGE) e++;
+                if (e > live) live = e;
+            }
+        F.maxe_live = (int) live;
+    }
     F.level = (int) cp->level; F.width = (int) job->image->width; F.height = (int) job->image->height;
     F.pool_max = (int) cp->pool_max_states; F.limit_states = (int) cp->limit_states;
     F.ML = (int) cp->limit_level;

@@ -55,6 +55,7 @@ typedef struct DevFrame {
     /* ---- parameters ---- */
     float    price;
     int      lc_min, lc_max, images_level, max_elements;
+    int      maxe_live;    /* edges per label any state of this frame can have: max(max_elements, basis) */
     int      gl0;          /* lowest level with a Gram table: min(lc_min, images_level) */
     int      second_domain_block;   /* codec/approx.c:103-118 (cfiasco -z 2) */
     int      check_underflow, check_overflow, full_search;   /* :119-206,420 (cfiasco -z 3) */

@@ -735,13 +735,14 @@ __device__ __forceinline__ void auto_tabs(const DevFrame &F, AutoTabs &t)
 
 /* the automaton rows of one state as they come out of memory: all edge slots are read
  * unconditionally (independent, coalesced loads; what lies behind the terminator is ignored) */
-struct EdgeRows {
-    int   tree[2], rd[2][FC_MAXE];
-    float rw[2][FC_MAXE];
+template <int E> struct EdgeRowsT {
+    int   tree[2], rd[2][E];
+    float rw[2][E];
     int   dt;
 };
+typedef EdgeRowsT<FC_MAXE> EdgeRows;
 
-__device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRows &r)
+template <int E> __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRowsT<E> &r)
 {
     unsigned us = (unsigned) s;
     /* opaque to loop strength reduction: otherwise every array gets its own 64-bit pointer
@@ -753,7 +754,7 @@ __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRow
         /* one scalar base per array, the row offset goes into the lane offset */
         r.tree[l] = ldg(T.tree, us + (unsigned) (l * T.PA));
 #pragma unroll
-        for (int e = 0; e < FC_MAXE; e++) {
+        for (int e = 0; e < E; e++) {
             r.rd[l][e] = ldg(T.into, us + (unsigned) ((l * 6 + e) * T.PA));
             r.rw[l][e] = ldg(T.weight, us + (unsigned) ((l * 6 + e) * T.PA));
         }
@@ -763,7 +764,9 @@ __device__ __forceinline__ void load_edge_rows(const AutoTabs &T, int s, EdgeRow
 /* <sub-block, state> tables for states [from, states) and the heap subtree under `image`
  * (codec/ip.c:72-154).  Per slot the additions run label 0 {child, edges}, label 1 {...}
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
-__device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
+/* E: edge slots per label read and summed (the build's E; 3 in the big build when neither the options nor
+ * the basis allow more: dead slots still cost a gather per slot and state) */
+template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level;
     const int P = __builtin_amdgcn_readfirstlane(F.P), states = __builtin_amdgcn_readfirstlane(table_states(sh));
@@ -790,18 +793,18 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
         /* the rows of the NEXT state of this lane are requested before the gathers of the
          * current one are waited for (one memory round trip per state instead of two) */
         int s = from + tid;
-        EdgeRows nx;
+        EdgeRowsT<E> nx;
         if (s < states) load_edge_rows(T, s, nx);
         for (; s < states; s += B) {
-            const EdgeRows cur = nx;
+            const EdgeRowsT<E> cur = nx;
             if (s + B < states) load_edge_rows(T, s + B, nx);
             const bool tabled = cur.dt && !DEAD(sh, s);
             if (!tabled) continue;
             /* term list of the state: per label the tree child (weight 1, added plain) and
              * the edges in stored order.  Fixed-trip, predicated loops so that all gathers
              * of a group of slots are in flight together (the chain is latency bound). */
-            int   idx[2][FC_MAXE + 1];
-            float wt[2][FC_MAXE + 1];
+            int   idx[2][E + 1];
+            float wt[2][E + 1];
             unsigned msk[2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
@@ -811,23 +814,23 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                 wt[l][0] = 1.0f;
                 bool live = true;
 #pragma unroll
-                for (int e = 0; e < FC_MAXE; e++) {
+                for (int e = 0; e < E; e++) {
                     live = live && cur.rd[l][e] != NOEDGE;
                     idx[l][e + 1] = live ? cur.rd[l][e] : 0;
                     wt[l][e + 1] = live ? cur.rw[l][e] : 0.0f;
                     msk[l] |= live ? (2u << e) : 0u;
                 }
             }
-            constexpr int JG = 4;          /* slots per group: 4 x 2 x (FC_MAXE + 1) gathers in flight per lane (8: -5 %) */
+            constexpr int JG = 4;          /* slots per group: 4 x 2 x (E + 1) gathers in flight per lane (8: -5 %) */
             for (int j0 = 0; j0 < cnt; j0 += JG) {
-                float v[JG][2][FC_MAXE + 1];
+                float v[JG][2][E + 1];
 #if FC_D5T
                 if (vec4) {
                     typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int l = 0; l < 2; l++)
 #pragma unroll
-                        for (int i = 0; i <= FC_MAXE; i++) {
+                        for (int i = 0; i <= E; i++) {
                             const unsigned o = (unsigned) idx[l][i] * NAu + (unsigned) l * NAh + (unsigned) (adr0 + j0);
                             const f4 q = *(GLOBAL_AS const f4 *) (src0 + o);
                             v[0][l][i] = q.x; v[1][l][i] = q.y; v[2][l][i] = q.z; v[3][l][i] = q.w;
@@ -838,7 +841,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
 #pragma unroll
                         for (int l = 0; l < 2; l++)
 #pragma unroll
-                            for (int i = 0; i <= FC_MAXE; i++) {
+                            for (int i = 0; i <= E; i++) {
                                 const int jc = j0 + jj < cnt ? j0 + jj : cnt - 1;
                                 v[jj][l][i] = ldg(src0, (unsigned) idx[l][i] * NAu + (unsigned) l * NAh + (unsigned) (adr0 + jc));
                             }
@@ -849,7 +852,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
 #pragma unroll
                     for (int l = 0; l < 2; l++)
 #pragma unroll
-                        for (int i = 0; i <= FC_MAXE; i++) {
+                        for (int i = 0; i <= E; i++) {
                             /* UNCONDITIONAL loads (dead terms read element 0 of the row, slots
                              * past the end re-read the last one): a conditional load becomes a
                              * branch with its own s_waitcnt and the gathers would run one
@@ -865,7 +868,7 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
                     for (int l = 0; l < 2; l++) {
                         if (msk[l] & 1u) acc += v[jj][l][0];
 #pragma unroll
-                        for (int i = 1; i <= FC_MAXE; i++)
+                        for (int i = 1; i <= E; i++)
                             if ((msk[l] >> i) & 1u) acc += wt[l][i] * v[jj][l][i];
                     }
                     stg(ipis, (unsigned) s + (unsigned) ((slot0 + j0 + jj) * P), acc);
@@ -874,6 +877,14 @@ __device__ __noinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restr
         }
         __syncthreads();
     }
+}
+
+__device__ __forceinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
+{
+#if FC_VARIANT_BIG
+    if (F.maxe_live <= 3) { op_ipis_t<3>(F, sh, image, address, level, from); return; }
+#endif
+    op_ipis_t<FC_MAXE>(F, sh, image, address, level, from);
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */

@@ -142,7 +142,8 @@ int     fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight
                                   /* 0: the label already has FA_MAXEDGES edges */
 int     fa_load_basis(const char *name, fa_wfa *w);   /* 1 ok / 0 error */
 
-/* the frame an automaton describes, 4:4:4, cropped to the coded size (decode_image,
+/* TEST ORACLE ONLY (oracle/oracle_decoder.c; the product decodes on the device, fa_core_decode_frames below):
+ * the frame an automaton describes, 4:4:4, cropped to the coded size (decode_image,
  * codec/decoder.c:411-536); NULL + message on failure */
 fa_image *fa_decode_image(unsigned orig_width, unsigned orig_height, const fa_wfa *w, int color);
 /* add the motion compensation of a P/B frame (restore_mc, codec/motion.c:37-229) */

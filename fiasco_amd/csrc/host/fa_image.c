@@ -69,6 +69,20 @@ int fa_pnm_header(const unsigned char *buf, size_t len, const char *name,
     return 1;
 }
 
+/* zeroed planes of the coder's 12.4 fixed point format */
+fa_image *fa_image_alloc(unsigned width, unsigned height, int color)
+{
+    fa_image *im = (fa_image *) calloc(1, sizeof *im);
+    int b;
+    if (!im) return NULL;
+    im->width = width; im->height = height; im->color = color;
+    for (b = 0; b < (color ? 3 : 1); b++) {
+        im->pixels[b] = (int16_t *) calloc((size_t) width * height, sizeof(int16_t));
+        if (!im->pixels[b]) { fa_image_free(im); return NULL; }
+    }
+    return im;
+}
+
 void fa_image_free(fa_image *im)
 {
     int b;

@@ -1869,7 +1869,7 @@ int fa_core_encode_frames(unsigned n, fa_job *jobs)
 
 const char *fa_core_name(void) { return "oracle-cpu"; }
 
-/* the decoder of the oracle build: the host restatement of codec/decoder.c / codec/motion.c (fa_decoder.c) */
+/* the decoder of the oracle build: the host restatement of codec/decoder.c / codec/motion.c (oracle_decoder.c) */
 int fa_core_decode_frames(unsigned n, fa_dec_job *jobs)
 {
     unsigned i;

@@ -1,5 +1,8 @@
 /*
- *  fa_decoder.c -- the frame an automaton describes, in the encoder's 12.4 fixed point planes.
+ *  oracle_decoder.c -- the frame an automaton describes, in the encoder's 12.4 fixed point planes.
+ *
+ *  TEST INFRASTRUCTURE (oracle library only): the CPU restatement of the reference's decoder.  The product
+ *  decodes on the device (fiasco_amd/csrc/hip/frame_decoder.inc) and does not contain this file.
  *
  *  The coder needs it after every frame of a video: the next P/B frame is predicted from the
  *  RECONSTRUCTED frame, not from the original (reference codec/coder.c:647-651).  Decoded
@@ -83,19 +86,6 @@ static const int16_t *state_image(dec *d, unsigned state, unsigned level)
         }
     }
     return buf;
-}
-
-fa_image *fa_image_alloc(unsigned width, unsigned height, int color)
-{
-    fa_image *im = (fa_image *) calloc(1, sizeof *im);
-    int b;
-    if (!im) return NULL;
-    im->width = width; im->height = height; im->color = color;
-    for (b = 0; b < (color ? 3 : 1); b++) {
-        im->pixels[b] = (int16_t *) calloc((size_t) width * height, sizeof(int16_t));
-        if (!im->pixels[b]) { fa_image_free(im); return NULL; }
-    }
-    return im;
 }
 
 /* decode_image (codec/decoder.c:411-536) for the 4:4:4 format the coder asks for */

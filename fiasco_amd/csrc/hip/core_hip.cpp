@@ -62,15 +62,15 @@ static thread_local DevState *t_dev = &g_state0;
 #define g_l2_err (t_dev->l2_err)
 
 extern "C" void fc_launch(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 extern "C" void fc_launch_big(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 extern "C" void fc_launch_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 extern "C" void fc_launch_wide_tri(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream);
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 
 /* block-level speculation (frame_coder.h, FcSpecCtl): n frames with G workgroups each */
 extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
@@ -167,6 +167,16 @@ static void cap_hint_put(const fa_job *job, int needP, int needPA)
 
 /* (fiasco_amd_get_stats / _reset_stats: with the multi-device entries, end of file) */
 static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ);
+/* workgroups per frame for the table passes of big frames (frame_coder.h FcCoop): the frames are launched in groups
+ * of eight (XCD placement), all workgroups must be resident at one per CU */
+static unsigned coop_policy(size_t frames, int cus)
+{
+    const size_t padded = (frames + 7) / 8 * 8;
+    if (padded * 4 <= (size_t) cus) return 4;
+    if (padded * 2 <= (size_t) cus) return 2;
+    return 1;
+}
+extern "C" unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus) { return coop_policy(frames, cus); }
 extern "C" int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int narrow_only, int occupancy)
 {
     return spec_policy(frames, cus, big_frames != 0, narrow_only != 0, occupancy);
@@ -518,6 +528,7 @@ struct Layout {
            final_d, level_of_state, domain_type, x, y, ycol, pool_states, pos, hits, ycol0, snap, pix16, total;
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
+    size_t coop;                                                            /* FcCoop: header + the block's pixels */
     int    max_save;
 };
 
@@ -580,6 +591,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(mc_fwd, inter ? (size_t) plevels * 1024 * 4 : 0);
     CARVE(mc_bwd, inter ? (size_t) plevels * 1024 * 4 : 0);
     CARVE(pix_chroma, inter && color ? npix / 3 * 2 * 2 : 0);
+    CARVE(coop, FC_COOP_HDR + ((size_t) (NS + 1) << il) * 4);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -906,6 +918,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.search_range = (int) cp->search_range;
     F.mv = (int16_t *) (base + L.mv);
     F.past = (const int16_t *) (base + L.past); F.future = (const int16_t *) (base + L.future);
+    F.coop = (FcCoop *) (base + L.coop);
     F.mc_fwd = (float *) (base + L.mc_fwd); F.mc_bwd = inter ? (float *) (base + L.mc_bwd) : nullptr;
     F.pix_chroma = (int16_t *) (base + L.pix_chroma);
     F.frame_type = job->frame_type;
@@ -1728,7 +1741,7 @@ static bool launch_wave(Staged *S)
     fail = fail || hipEventRecord(S->ev0, S->stream) != hipSuccess;
     {
         typedef void (*launch_fn)(DevFrame *, unsigned, unsigned, unsigned long long *, unsigned *, const unsigned *,
-                                  unsigned long long, hipStream_t);
+                                  unsigned long long, unsigned, hipStream_t);
         /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
         unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
         if (fa_knob("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_QUEUE_WAIT_MS"));
@@ -1753,17 +1766,44 @@ static bool launch_wave(Staged *S)
                     fail = fail || hipMemcpyAsync(S->d_frames + at, hf.data() + at, sizeof(DevFrame) * nq,
                                                   hipMemcpyHostToDevice, S->stream) != hipSuccess;
                     if (group_lend[g])
-                        launch[g](S->d_frames + at, (unsigned) group_lend[g], (unsigned) group_lend[g], nullptr, nullptr, nullptr, qwait, S->stream);
+                        launch[g](S->d_frames + at, (unsigned) group_lend[g], (unsigned) group_lend[g], nullptr, nullptr, nullptr, qwait, 1u, S->stream);
                 } else {
                     unsigned long long *ring = S->d_ring + (size_t) g * batch.size();
                     fail = fail || hipMemsetAsync(S->d_queue + 2 * g, 0, 2 * sizeof(unsigned), S->stream) != hipSuccess;
                     fail = fail || hipMemsetAsync(ring, 0, nq * sizeof(unsigned long long), S->stream) != hipSuccess;
                     launch[g](S->d_frames + at, (unsigned) nq, (unsigned) group_lend[g], ring, S->d_queue + 2 * g,
-                              S->d_ptrmask, qwait, S->stream);
+                              S->d_ptrmask, qwait, 1u, S->stream);
                 }
                 at += nq; plain -= nq;
             }
-            if (plain) launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, qwait, S->stream);
+            if (plain) {
+                /* big frames that leave the chip empty (a step of a video: 30 GOPs): several workgroups build the
+                 * tables of a frame (frame_coder.h FcCoop).  One workgroup of 512 threads per CU; every workgroup
+                 * of the launch must be resident: W x frames <= CUs, and nothing else launched beside it */
+                unsigned W = 1;
+                if (g == 3 && batch.size() == plain) {
+                    W = coop_policy(plain, S->ncu ? S->ncu : 256);
+                    if (fa_knob("FIASCO_AMD_COOP") && atoi(fa_knob("FIASCO_AMD_COOP")) >= 1) {
+                        W = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP"));
+                        if (W > 8) W = 8;
+                        if ((size_t) W * ((plain + 7) / 8 * 8) > (size_t) (S->ncu ? S->ncu : 256)) W = 1;
+                    }
+                }
+                if (W > 1) {
+                    static FcCoop zero[4];                 /* [d]: header of a frame with depth d */
+                    unsigned D = 1;
+                    while ((1u << D) < W) D++;
+                    if (fa_knob("FIASCO_AMD_COOP_DEPTH") && atoi(fa_knob("FIASCO_AMD_COOP_DEPTH")) >= 1 && atoi(fa_knob("FIASCO_AMD_COOP_DEPTH")) <= 3
+                        && (1 << atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"))) >= (int) W)
+                        D = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"));
+                    memset(&zero[D], 0, sizeof zero[D]);
+                    zero[D].depth = D;
+                    for (size_t b = at; b < at + plain && !fail; b++)
+                        fail = hipMemcpyAsync(hf[b].coop, &zero[D], sizeof(FcCoop), hipMemcpyHostToDevice, S->stream) != hipSuccess;
+                    g_stats.coop_frames += plain; g_stats.coop_workgroups = W;
+                }
+                launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, qwait, W, S->stream);
+            }
             first += group_n[g];
         }
     }
@@ -1916,6 +1956,7 @@ static void complete_wave(Staged *S)
             if (st == FC_ERR_STATES || st == FC_ERR_CAPACITY) msg = "Maximum number of states reached!";
             else if (st == FC_ERR_NOROOT) msg = "No root state generated!";
             else if (st == FC_ERR_QUEUE) msg = "device coder: frame queue gave no slab";
+            else if (st == FC_ERR_COOP) msg = "device coder: the helper workgroups of the frame did not answer";
             else if (st == FC_ERR_INTERNAL) msg = "device coder: frame exceeds a built-in capacity (recursion depth, snapshot stack or 16384 states)";
             if (st > FC_ERR_QUEUE) snprintf(job->errmsg, sizeof job->errmsg, "%s (status %d)", msg, st);
             else snprintf(job->errmsg, sizeof job->errmsg, "%s", msg);

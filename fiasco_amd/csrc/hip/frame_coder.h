@@ -47,7 +47,27 @@
 #define FC_TRI_HOT  8           /* states whose Gram columns the triangular layout also keeps as rows (DevFrame.gcol) */
 
 enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5,
-       FC_ERR_QUEUE = 6 };    /* frame queue: no free slab arrived in time, encode again with a slab of its own */
+       FC_ERR_QUEUE = 6,      /* frame queue: no free slab arrived in time, encode again with a slab of its own */
+       FC_ERR_COOP = 7 };     /* the helper workgroups of a frame did not answer in time (FcCoop) */
+/* Several workgroups for the TABLE passes of one frame (big build, launches that leave the chip empty; round 4).
+ * The <sub-block, state> tables of a block (init_range, codec/ip.c:72-154) and of a residual block
+ * (codec/prediction.c:302-309) are a third of a predicted frame's time, and the subtrees below depth D of the block
+ * do not depend on each other: workgroup m of the frame builds the level-5 dots and the level recursion of the
+ * subtrees m, m + W, ... for ALL states; the frame's own workgroup (m = 0) then adds the top D levels.  One
+ * hand-off each way per block: pixels + descriptor -> release -> seq; helpers: acquire, work, release -> done.
+ * Same operations on the same operands in the same order per table entry: the values cannot differ. */
+struct FcCoop {
+    unsigned seq;            /* table builds published by the frame's workgroup */
+    unsigned done;           /* arrivals of the helpers: W - 1 per build */
+    unsigned quit;           /* the frame is finished */
+    unsigned depth;          /* D: 2^D subtrees */
+    int      level, from, to, pad;
+    float   *ipis, *d5, *d4; /* the active table set (prediction swaps it) */
+    /* the block's pixels (floats) follow at byte FC_COOP_HDR */
+};
+#define FC_COOP_HDR 128
+#define FC_COOP_WAIT_TICKS 3000000000ull        /* helpers give up after 30 s without work (100 MHz wall clock) */
+#define FC_COOP_DONE_TICKS 500000000ull         /* the frame waits 5 s for its helpers, then fails with FC_ERR_COOP */
 #define FC_QUEUE_WAIT_TICKS 60000000000ull      /* default bound of that wait: 10 minutes of the 100 MHz wall clock */
 
 struct FcTrace;
@@ -140,6 +160,7 @@ typedef struct DevFrame {
     /* ---- results ---- */
     int      status;
     int      states, root_state;
+    FcCoop  *coop;         /* several workgroups per frame for the table passes (nullptr: one) */
     int      ystates_out;  /* states that own tables (gray / Y band) at the end: the host's capacity memory */
     float    costs, err, tree_bits, matrix_bits, weights_bits;      /* band 0 (gray / Y) */
     float    c_costs[2], c_err[2], c_tree_bits[2], c_matrix_bits[2], c_weights_bits[2];  /* Cb, Cr */

@@ -306,6 +306,9 @@ struct Sh {
     SFrame   st[FC_DEPTH];
     int      sp;
     int      op, a0, a1, a2, a3;
+#if FC_VARIANT_BIG
+    unsigned coopW, coop_seq;      /* workgroups of this frame (FcCoop), table builds published so far */
+#endif
     Pool     pool;
     CoeffBuf cb;
 #if FC_VARIANT_BIG
@@ -766,7 +769,7 @@ template <int E> __device__ __forceinline__ void load_edge_rows(const AutoTabs &
  * onto zero, which is the reference's accumulation order onto its zeroed slots. */
 /* E: edge slots per label read and summed (the build's E; 3 in the big build when neither the options nor
  * the basis allow more: dead slots still cost a gather per slot and state) */
-template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
+template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from, int lv_first)
 {
     const int tid = threadIdx.x, il = F.images_level;
     const int P = __builtin_amdgcn_readfirstlane(F.P), states = __builtin_amdgcn_readfirstlane(table_states(sh));
@@ -776,7 +779,8 @@ template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restri
     GLOBAL_AS const float *const d5 = uniform_ptr((const float *) ACT_D5(F, sh));
     AutoTabs T;
     auto_tabs(F, T);
-    for (int lv = il + 1; lv <= level; lv++) {
+    lv_first = __builtin_amdgcn_readfirstlane(lv_first);
+    for (int lv = lv_first > il + 1 ? lv_first : il + 1; lv <= level; lv++) {
         int delta = level - lv;
         int cnt = 1 << delta;
         int slot0 = ((image + 1) << delta) - 1;
@@ -879,18 +883,22 @@ template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restri
     }
 }
 
-__device__ __forceinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from)
+/* lv_first: the levels below it are in the tables already (a cooperative build, FcCoop) */
+__device__ __forceinline__ void op_ipis(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int image, int address, int level, int from,
+                                        int lv_first = 0)
 {
 #if FC_VARIANT_BIG
-    if (F.maxe_live <= 3) { op_ipis_t<3>(F, sh, image, address, level, from); return; }
+    if (F.maxe_live <= 3) { op_ipis_t<3>(F, sh, image, address, level, from, lv_first); return; }
 #endif
-    op_ipis_t<FC_MAXE>(F, sh, image, address, level, from);
+    op_ipis_t<FC_MAXE>(F, sh, image, address, level, from, lv_first);
 }
 
 /* level-images_level dots of the current pixel block with state images (codec/ip.c:268-295) */
 /* na / n4: number of level-images_level and level-(images_level - 1) sub-blocks of the block in
  * sh.pixels (NA and 2 NA for a whole block; fewer for the residual of a predicted range) */
-__device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to, int na, int n4)
+/* abase / pxoff: the addresses start at abase (level images_level; 2 abase one level below) and their pixels at
+ * sh.pixels + pxoff -- one subtree of a block (cooperative build, FcCoop) */
+__device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int from, int to, int na, int n4, int abase = 0, int pxoff = 0)
 {
     const int tid = threadIdx.x, P = __builtin_amdgcn_readfirstlane(F.P);
     /* tables behind scalar bases: global_load / global_store with a 32-bit lane offset (through the generic
@@ -944,12 +952,12 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
             f2 ip = { 0.0f, 0.0f };
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                f2 px = { sh.pixels[a * 32 + k], sh.pixels[a * 32 + 32 + k] };
+                f2 px = { sh.pixels[pxoff + a * 32 + k], sh.pixels[pxoff + a * 32 + 32 + k] };
                 f2 vv = { v[k], v[k] };
                 ip = ip + px * vv;
             }
-            stg(D5, (unsigned) (a * P + s), ip.x);
-            if (a + 1 < na) stg(D5, (unsigned) ((a + 1) * P + s), ip.y);
+            stg(D5, (unsigned) ((abase + a) * P + s), ip.x);
+            if (a + 1 < na) stg(D5, (unsigned) ((abase + a + 1) * P + s), ip.y);
         }
 #endif
 #if FC_VARIANT_BIG
@@ -960,13 +968,113 @@ __device__ void op_d5(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int f
             for (int a = 0; a < n4; a++) {
                 float ip = 0;
 #pragma unroll
-                for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v[k];
-                D4[(size_t) a * P + s] = ip;
+                for (int k = 0; k < 16; k++) ip += sh.pixels[pxoff + a * 16 + k] * v[k];
+                D4[(size_t) (2 * abase + a) * P + s] = ip;
             }
         }
 #endif
     }
 }
+
+#if FC_VARIANT_BIG
+/* ---- several workgroups for the table passes of one frame (frame_coder.h, FcCoop) ---- */
+__device__ __forceinline__ float *coop_pixels(FcCoop *c) { return (float *) ((char *) c + FC_COOP_HDR); }
+
+/* the subtrees member, member + W, ... of depth D below a block of 2^level pixels in sh.pixels: level-5 dots and
+ * the level recursion up to the subtree's own level, for the states [from, table_states) */
+__device__ void coop_share(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int from, unsigned member, unsigned W, int D)
+{
+    const int il = F.images_level, sub = level - D, nasub = 1 << (sub - il);
+    for (int j = (int) member; j < (1 << D); j += (int) W)
+        op_d5(F, sh, from, table_states(sh), nasub, 2 * nasub, j * nasub, j << sub);
+    __syncthreads();
+    for (int j = (int) member; j < (1 << D); j += (int) W)
+        op_ipis(F, sh, (1 << D) - 1 + j, j, sub, from);
+}
+
+/* The frame's workgroup: hand the block in sh.pixels to the helpers, build the own share, wait for theirs.
+ * Returns the depth D (the caller adds the levels above level - D), or 0: the block is built the ordinary way. */
+__device__ int coop_build(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int from)
+{
+    const int tid = threadIdx.x, il = F.images_level;
+    const unsigned W = sh.coopW;
+    FcCoop *c = F.coop;
+    if (W < 2 || !c) return 0;
+    const int D = (int) c->depth;
+    if (level - il < D + 2) return 0;                       /* subtrees of fewer than four addresses: not worth a hand-off */
+    float *gp = coop_pixels(c);
+    for (int i = tid; i < (1 << level); i += B) gp[i] = sh.pixels[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        c->level = level; c->from = from; c->to = table_states(sh);
+        c->ipis = sh.par.ipis; c->d5 = sh.par.d5; c->d4 = sh.par.d4;
+        /* everything the helpers read: the pixels, the descriptor, the rows of the states appended so far */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh.coop_seq++;
+        __hip_atomic_store(&c->seq, sh.coop_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    coop_share(F, sh, level, from, 0, W, D);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned want = sh.coop_seq * (W - 1);
+        const unsigned long long t_give_up = wall_clock64() + FC_COOP_DONE_TICKS;
+        while (__hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (wall_clock64() > t_give_up) { sh.failed = FC_ERR_COOP; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the helpers' rows, not this CU's stale lines */
+    }
+    __syncthreads();
+    return D;
+}
+
+/* workgroups 1 .. W - 1 of a frame: build what the frame's workgroup hands over until it is finished */
+__device__ void coop_helper(DevFrame &__restrict__ F, Sh &__restrict__ sh, unsigned member, unsigned W)
+{
+    const int tid = threadIdx.x;
+    FcCoop *c = F.coop;
+    unsigned seen = 0;
+    if (!c) return;
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long t_give_up = wall_clock64() + FC_COOP_WAIT_TICKS;
+            int go = 0;
+            for (;;) {
+                if (__hip_atomic_load(&c->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { go = -1; break; }
+                if (__hip_atomic_load(&c->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seen) { go = 1; break; }
+                if (wall_clock64() > t_give_up) { go = -1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (go == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                sh.a0 = c->level; sh.a1 = c->from; sh.a2 = (int) c->depth;
+                sh.band = 0; sh.states = c->to; sh.ystates = c->to;
+                sh.par.ipis = c->ipis; sh.par.d5 = c->d5; sh.par.d4 = c->d4;
+            }
+            sh.op = go;
+        }
+        __syncthreads();
+        if (sh.op < 0) return;
+        const int level = sh.a0, from = sh.a1, D = sh.a2, sub = level - D;
+        const float *gp = coop_pixels(c);
+        for (int j = (int) member; j < (1 << D); j += (int) W)
+            for (int i = tid; i < (1 << sub); i += B) sh.pixels[(j << sub) + i] = gp[(j << sub) + i];
+        __syncthreads();
+        coop_share(F, sh, level, from, member, W, D);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&c->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        seen++;
+        __syncthreads();                /* sh.op is rewritten by lane 0 at the top */
+    }
+}
+#endif
 
 /* codec/subdivide.c:504-541,612-644 */
 /* from: the entries of the states below it are in the tables already (FC_SPEC: a table worker has
@@ -1025,12 +1133,20 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tp0 = wall_clock64();
 #endif
+#if FC_VARIANT_BIG
+    const int coopD = coop_build(F, sh, level, from);        /* (sh.pixels is complete: the norms only read it) */
+    if (coopD) op_ipis(F, sh, 0, 0, level, from, level - coopD + 1);
+    else {
+#endif
     op_d5(F, sh, from, table_states(sh), F.NA, 2 * F.NA);
     __syncthreads();
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) { unsigned long long t = wall_clock64(); sh.tk_init[0] += t - tp0; tp0 = t; }
 #endif
     op_ipis(F, sh, 0, 0, level, from);
+#if FC_VARIANT_BIG
+    }
+#endif
 #ifdef FC_SERIAL_PROFILE
     if (tid == 0) sh.tk_init[1] += wall_clock64() - tp0;
 #endif
@@ -1685,6 +1801,10 @@ __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restr
     __syncthreads();
     /* tables of the residual block for every state (compute_ip_images_state(0, 0, level, 1, 0)) */
     if (level > il) block_norms(sh, level, (1 << (level - il)) - 1);
+    {
+        const int coopD = coop_build(F, sh, level, 0);
+        if (coopD) { op_ipis(F, sh, 0, 0, level, 0, level - coopD + 1); return; }
+    }
     op_d5(F, sh, 0, table_states(sh), level >= il ? 1 << (level - il) : 0, level >= il - 1 ? 1 << (level - il + 1) : 0);
     __syncthreads();
     if (level > il) op_ipis(F, sh, 0, 0, level, 0);
@@ -3029,7 +3149,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU)
 FC_KERNEL(DevFrame *frames, DevFrame *vframes, unsigned G)
 #else
 FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask,
-          unsigned long long queue_wait_ticks)
+          unsigned long long queue_wait_ticks, unsigned coopW)
 #endif
 {
     __shared__ Sh sh;
@@ -3041,6 +3161,20 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     const unsigned role = blockIdx.x % G;
     DevFrame &F = role ? vframes[(blockIdx.x / G) * (G - 1) + role - 1] : frames[blockIdx.x / G];
     unsigned long long *const ring = nullptr;
+#elif FC_VARIANT_BIG
+    /* coopW > 1: that many workgroups per frame (FcCoop; nlend = frames, no queue).  The workgroups of a frame get
+     * block ids that differ by multiples of 8: the same XCD where the dispatcher deals blocks round robin -- a
+     * matter of speed only, the hand-offs are agent-scope release / acquire */
+    const unsigned cW = coopW > 1 ? coopW : 1;
+    unsigned fidx = blockIdx.x, member = 0;
+    if (cW > 1) {
+        fidx = (blockIdx.x / (8 * cW)) * 8 + blockIdx.x % 8;
+        member = (blockIdx.x / 8) % cW;
+        if (fidx >= nlend) return;
+    }
+    DevFrame &F = frames[fidx];
+    if (member) { coop_helper(F, sh, member, cW); return; }
+    if (threadIdx.x == 0) { sh.coopW = F.coop ? cW : 1; sh.coop_seq = 0; }
 #else
     DevFrame &F = frames[blockIdx.x];
 #endif
@@ -3693,6 +3827,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #endif
     if (tid == 0) {
         /* per-band results and the root state were recorded by band_advance() */
+#if FC_VARIANT_BIG && !FC_SPEC
+        if (sh.coopW > 1 && F.coop) __hip_atomic_store(&F.coop->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         F.states = sh.states;
         F.ystates_out = sh.band ? sh.ystates : sh.states;
         F.lc_min_out = sh.lc_min;
@@ -3742,8 +3879,10 @@ extern "C" unsigned fc_spec_ctl_bytes(void) { return (unsigned) ((sizeof(FcSpecC
 #endif
 #else
 extern "C" void FC_LAUNCH(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
-                          const unsigned *ptrmask, unsigned long long queue_wait_ticks, hipStream_t stream)
+                          const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream)
 {
-    hipLaunchKernelGGL(FC_KERNEL, dim3(n), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask, queue_wait_ticks);
+    /* coopW > 1 (big builds, no queue): coopW workgroups per frame, frames in groups of eight (kernel entry) */
+    const unsigned grid = coopW > 1 ? (n + 7) / 8 * 8 * coopW : n;
+    hipLaunchKernelGGL(FC_KERNEL, dim3(grid), dim3(B), 0, stream, d_frames, nlend, ring, ctr, ptrmask, queue_wait_ticks, coopW);
 }
 #endif

@@ -49,6 +49,8 @@ typedef struct fiasco_amd_stats {
      * (2 bytes per pixel of every level image written and per (pixel, term) read, + the frame), device time of
      * the flights in microseconds (HIP events around uploads + kernels of a flight of <= 32 frames) */
     unsigned long long decoder_frames, decoder_bytes, decoder_us;
+    /* big frames whose table passes were built by several workgroups (frame_coder.h FcCoop), and how many each */
+    unsigned long long coop_frames, coop_workgroups;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);
@@ -74,6 +76,9 @@ const char *fa_core_name(void);
  * fiasco_amd_set_device() (one process per GPU: the multi-process harness); else every visible device.
  * An id may be listed twice (two shares on one GPU).  Replacement of staged inputs
  * (fiasco_amd_batch_upload) needs a single device.  All return 1 on success, 0 + error message. */
+/* workgroups per frame the launcher gives the table passes of `frames` big frames (prediction, P/B frames, -z 1/2)
+ * on a chip of `cus` CUs: 1, 2 or 4 (csrc/hip/frame_coder.h FcCoop); pure function */
+unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus);
 int fiasco_amd_set_device(int device);
 int fiasco_amd_set_devices(const int *ids, int n);      /* n = 0: back to the automatic choice */
 int fiasco_amd_device_count(void);                      /* shares a batch is split into */

@@ -172,6 +172,7 @@ static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only
 static unsigned coop_policy(size_t frames, int cus)
 {
     const size_t padded = (frames + 7) / 8 * 8;
+    if (padded * 8 <= (size_t) cus) return 8;
     if (padded * 4 <= (size_t) cus) return 4;
     if (padded * 2 <= (size_t) cus) return 2;
     return 1;
@@ -1798,6 +1799,7 @@ static bool launch_wave(Staged *S)
                         D = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"));
                     memset(&zero[D], 0, sizeof zero[D]);
                     zero[D].depth = D;
+                    zero[D].minsub = fa_knob("FIASCO_AMD_COOP_MINSUB") ? atoi(fa_knob("FIASCO_AMD_COOP_MINSUB")) : 1;
                     for (size_t b = at; b < at + plain && !fail; b++)
                         fail = hipMemcpyAsync(hf[b].coop, &zero[D], sizeof(FcCoop), hipMemcpyHostToDevice, S->stream) != hipSuccess;
                     g_stats.coop_frames += plain; g_stats.coop_workgroups = W;

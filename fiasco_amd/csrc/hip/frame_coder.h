@@ -61,7 +61,8 @@ struct FcCoop {
     unsigned done;           /* arrivals of the helpers: W - 1 per build */
     unsigned quit;           /* the frame is finished */
     unsigned depth;          /* D: 2^D subtrees */
-    int      level, from, to, pad;
+    int      level, from, to;
+    int      minsub;         /* blocks whose subtrees have fewer than 2^minsub level-5 addresses are built the ordinary way */
     float   *ipis, *d5, *d4; /* the active table set (prediction swaps it) */
     /* the block's pixels (floats) follow at byte FC_COOP_HDR */
 };

@@ -308,6 +308,7 @@ struct Sh {
     int      op, a0, a1, a2, a3;
 #if FC_VARIANT_BIG
     unsigned coopW, coop_seq;      /* workgroups of this frame (FcCoop), table builds published so far */
+    int      coopD, coop_minsub;   /* FcCoop.depth / .minsub */
 #endif
     Pool     pool;
     CoeffBuf cb;
@@ -992,16 +993,16 @@ __device__ void coop_share(const DevFrame &__restrict__ F, Sh &__restrict__ sh, 
         op_ipis(F, sh, (1 << D) - 1 + j, j, sub, from);
 }
 
-/* The frame's workgroup: hand the block in sh.pixels to the helpers, build the own share, wait for theirs.
- * Returns the depth D (the caller adds the levels above level - D), or 0: the block is built the ordinary way. */
-__device__ int coop_build(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int from)
+/* The frame's workgroup: hand the block in sh.pixels to the helpers.  Returns the depth D (the caller goes on
+ * with coop_finish and adds the levels above level - D), or 0: the block is built the ordinary way. */
+__device__ int coop_publish(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int from)
 {
     const int tid = threadIdx.x, il = F.images_level;
     const unsigned W = sh.coopW;
     FcCoop *c = F.coop;
     if (W < 2 || !c) return 0;
-    const int D = (int) c->depth;
-    if (level - il < D + 2) return 0;                       /* subtrees of fewer than four addresses: not worth a hand-off */
+    const int D = sh.coopD;
+    if (level - il < D + sh.coop_minsub) return 0;          /* small subtrees: not worth a hand-off */
     float *gp = coop_pixels(c);
     for (int i = tid; i < (1 << level); i += B) gp[i] = sh.pixels[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1015,6 +1016,15 @@ __device__ int coop_build(DevFrame &__restrict__ F, Sh &__restrict__ sh, int lev
         sh.coop_seq++;
         __hip_atomic_store(&c->seq, sh.coop_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return D;
+}
+
+/* ... after the caller's own LDS-only work (the norms of the block): the own share, then the helpers' */
+__device__ void coop_finish(DevFrame &__restrict__ F, Sh &__restrict__ sh, int level, int from, int D)
+{
+    const int tid = threadIdx.x;
+    const unsigned W = sh.coopW;
+    FcCoop *c = F.coop;
     coop_share(F, sh, level, from, 0, W, D);
     __syncthreads();
     if (tid == 0) {
@@ -1027,7 +1037,6 @@ __device__ int coop_build(DevFrame &__restrict__ F, Sh &__restrict__ sh, int lev
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the helpers' rows, not this CU's stale lines */
     }
     __syncthreads();
-    return D;
 }
 
 /* workgroups 1 .. W - 1 of a frame: build what the frame's workgroup hands over until it is finished */
@@ -1115,6 +1124,10 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
         }
     }
     __syncthreads();
+#if FC_VARIANT_BIG
+    /* the helpers start on the block while this workgroup sums the norms (LDS only) */
+    const int coopD = coop_publish(F, sh, level, from);
+#endif
     /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
     for (int slot = tid; slot < F.NS; slot += B) {
         int depth = 31 - __clz(slot + 1);
@@ -1134,9 +1147,10 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     unsigned long long tp0 = wall_clock64();
 #endif
 #if FC_VARIANT_BIG
-    const int coopD = coop_build(F, sh, level, from);        /* (sh.pixels is complete: the norms only read it) */
-    if (coopD) op_ipis(F, sh, 0, 0, level, from, level - coopD + 1);
-    else {
+    if (coopD) {
+        coop_finish(F, sh, level, from, coopD);
+        op_ipis(F, sh, 0, 0, level, from, level - coopD + 1);
+    } else {
 #endif
     op_d5(F, sh, from, table_states(sh), F.NA, 2 * F.NA);
     __syncthreads();
@@ -1800,10 +1814,14 @@ __device__ __noinline__ void op_pred_setup(DevFrame &__restrict__ F, Sh &__restr
     swap_model_sets(sh);
     __syncthreads();
     /* tables of the residual block for every state (compute_ip_images_state(0, 0, level, 1, 0)) */
-    if (level > il) block_norms(sh, level, (1 << (level - il)) - 1);
     {
-        const int coopD = coop_build(F, sh, level, 0);
-        if (coopD) { op_ipis(F, sh, 0, 0, level, 0, level - coopD + 1); return; }
+        const int coopD = coop_publish(F, sh, level, 0);
+        if (level > il) block_norms(sh, level, (1 << (level - il)) - 1);
+        if (coopD) {
+            coop_finish(F, sh, level, 0, coopD);
+            op_ipis(F, sh, 0, 0, level, 0, level - coopD + 1);
+            return;
+        }
     }
     op_d5(F, sh, 0, table_states(sh), level >= il ? 1 << (level - il) : 0, level >= il - 1 ? 1 << (level - il + 1) : 0);
     __syncthreads();
@@ -3174,7 +3192,10 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     }
     DevFrame &F = frames[fidx];
     if (member) { coop_helper(F, sh, member, cW); return; }
-    if (threadIdx.x == 0) { sh.coopW = F.coop ? cW : 1; sh.coop_seq = 0; }
+    if (threadIdx.x == 0) {
+        sh.coopW = F.coop ? cW : 1; sh.coop_seq = 0;
+        sh.coopD = cW > 1 && F.coop ? (int) F.coop->depth : 0; sh.coop_minsub = cW > 1 && F.coop ? F.coop->minsub : 0;
+    }
 #else
     DevFrame &F = frames[blockIdx.x];
 #endif

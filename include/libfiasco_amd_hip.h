@@ -77,7 +77,7 @@ const char *fa_core_name(void);
  * An id may be listed twice (two shares on one GPU).  Replacement of staged inputs
  * (fiasco_amd_batch_upload) needs a single device.  All return 1 on success, 0 + error message. */
 /* workgroups per frame the launcher gives the table passes of `frames` big frames (prediction, P/B frames, -z 1/2)
- * on a chip of `cus` CUs: 1, 2 or 4 (csrc/hip/frame_coder.h FcCoop); pure function */
+ * on a chip of `cus` CUs: 1, 2, 4 or 8 (csrc/hip/frame_coder.h FcCoop); pure function */
 unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus);
 int fiasco_amd_set_device(int device);
 int fiasco_amd_set_devices(const int *ids, int n);      /* n = 0: back to the automatic choice */

@@ -26,7 +26,9 @@
 #include <string.h>
 #include <ctype.h>
 #include <math.h>
+#include <pthread.h>
 #include <time.h>
+#include <unistd.h>
 #include "fa_host.h"
 
 /* developer aid: FIASCO_AMD_SEQ_TIMING=1 prints where a sweep spends its time (stderr) */
@@ -198,6 +200,32 @@ typedef struct gop_run {
     unsigned carry;
 } gop_run;
 
+/* parsing the inputs of one step: share `first, first + stride, ...' of the running GOPs */
+#define PARSE_THREADS 16
+typedef struct parsed { fa_image *im; char err[160]; } parsed;
+typedef struct parse_share {
+    fa_seq *s;
+    const gop_run *run;
+    parsed *pre;
+    unsigned nrun, step, first, stride;
+} parse_share;
+static void *parse_thread(void *arg)
+{
+    parse_share *p = (parse_share *) arg;
+    fa_seq *s = p->s;
+    unsigned r;
+    for (r = p->first; r < p->nrun; r += p->stride) {
+        const gop_run *q = &p->run[r];
+        unsigned k;
+        p->pre[r].im = NULL; p->pre[r].err[0] = 0;
+        if (q->dead || p->step >= q->n) continue;
+        k = s->gfirst[q->g] + p->step;
+        p->pre[r].im = fa_image_from_pnm(s->bufs[s->order[k]], s->lens[s->order[k]], s->names ? s->names[s->order[k]] : "<memory>");
+        if (!p->pre[r].im) snprintf(p->pre[r].err, sizeof p->pre[r].err, "%s", fiasco_get_error_message());   /* this thread's message */
+    }
+    return NULL;
+}
+
 /* Partition search of the GOPs of this rank marked in todo[], each starting from carry_in[g].
  * Frame j of all of them is one batch for the core.  Returns 0 only on an internal error (out of
  * memory); a GOP whose search fails is recorded (fa_seq_gop_result) -- whether that is an error
@@ -211,10 +239,11 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     unsigned *who = (unsigned *) calloc(s->ngop ? s->ngop : 1, sizeof *who);
     uint8_t *need = (uint8_t *) calloc(s->ngop ? s->ngop : 1, 1);
     fa_dec_job *djobs = (fa_dec_job *) calloc(s->ngop ? s->ngop : 1, sizeof *djobs);
+    parsed *pre = (parsed *) calloc(s->ngop ? s->ngop : 1, sizeof *pre);
     unsigned nrun = 0, g, r, step, maxlen = 0;
     int rc = 0;
     double t_prep = 0, t_core = 0, t_dec = 0, t0;
-    if (!run || !jobs || !ims || !who || !need || !djobs) { fa_set_error("Out of memory!"); goto out; }
+    if (!run || !jobs || !ims || !who || !need || !djobs || !pre) { fa_set_error("Out of memory!"); goto out; }
     for (g = 0; g < s->ngop; g++) {
         unsigned k;
         if (!fa_seq_is_mine(s, g) || !todo[g]) continue;
@@ -227,6 +256,19 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     for (step = 0; step < maxlen; step++) {
         t0 = seq_now();
         unsigned nb = 0, b;
+        /* the inputs of this step: PNM -> planes of every GOP's frame side by side on the host's cores */
+        {
+            parse_share sh[PARSE_THREADS];
+            pthread_t th[PARSE_THREADS];
+            int started[PARSE_THREADS] = { 0 };
+            long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+            unsigned nt = ncpu > PARSE_THREADS ? PARSE_THREADS : ncpu < 1 ? 1 : (unsigned) ncpu, t;
+            if (nt > nrun) nt = nrun ? nrun : 1;
+            for (t = 0; t < nt; t++) { sh[t].s = s; sh[t].run = run; sh[t].pre = pre; sh[t].nrun = nrun; sh[t].step = step; sh[t].first = t; sh[t].stride = nt; }
+            for (t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, parse_thread, &sh[t]) == 0;
+            parse_thread(&sh[0]);
+            for (t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else parse_thread(&sh[t]); }
+        }
         for (r = 0; r < nrun; r++) {
             gop_run *q = &run[r];
             unsigned k;
@@ -249,9 +291,8 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
                 fa_image_free(q->reconst); q->reconst = NULL;
             }
             q->last_was_future = s->isfut[k];
-            ims[nb] = fa_image_from_pnm(s->bufs[s->order[k]], s->lens[s->order[k]],
-                                        s->names ? s->names[s->order[k]] : "<memory>");
-            if (!ims[nb]) { snprintf(s->gerr[q->g], 160, "%s", fiasco_get_error_message()); s->gfail[q->g] = 1; q->dead = 1; continue; }
+            ims[nb] = pre[r].im; pre[r].im = NULL;             /* parsed side by side above */
+            if (!ims[nb]) { snprintf(s->gerr[q->g], 160, "%s", pre[r].err); s->gfail[q->g] = 1; q->dead = 1; continue; }
             memset(&jobs[nb], 0, sizeof jobs[nb]);
             jobs[nb].image = ims[nb];
             jobs[nb].cp = s->cp;
@@ -339,6 +380,8 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
 out:
     for (r = 0; run && r < nrun; r++) { fa_image_free(run[r].reconst); fa_image_free(run[r].past); fa_image_free(run[r].future); }
     free(run); free(jobs); free(ims); free(who); free(need); free(djobs);
+    for (r = 0; pre && r < nrun; r++) fa_image_free(pre[r].im);
+    free(pre);
     return rc;
 }
 

@@ -48,6 +48,17 @@ def test_workgroups_per_frame_of_a_launch(product):
     assert f(0, 256, 0, 1, 5) == 0 and f(4, 0, 0, 1, 5) == 0
 
 
+def test_workgroups_for_the_tables_of_big_frames(product):
+    """The launcher's policy for big frames (prediction, P/B frames, -z 1/2) that leave the chip empty: several
+    workgroups build the <sub-block, state> tables of a frame (csrc/hip/frame_coder.h FcCoop).  Frames are launched in
+    groups of eight, every workgroup must be resident at one per CU: BASELINE config 5 (30 GOPs side by side) gets 8."""
+    f = product.L.fiasco_amd_coop_workgroups
+    f.restype = ctypes.c_uint
+    f.argtypes = [ctypes.c_uint, ctypes.c_int]
+    assert [f(n, 256) for n in (1, 8, 30, 32, 33, 64, 65, 128, 129, 256)] == [8, 8, 8, 8, 4, 4, 2, 2, 1, 1]
+    assert [f(n, 64) for n in (1, 8, 9, 16, 17, 32, 33)] == [8, 8, 4, 4, 2, 2, 1]
+
+
 def test_no_oracle_in_product():
     """The product library must not link or contain the CPU oracle."""
     out = subprocess.run(["nm", "-D", fiasco_amd.LIB_PATH], capture_output=True, text=True).stdout

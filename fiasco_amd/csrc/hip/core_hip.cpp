@@ -733,6 +733,7 @@ struct Staged {
     unsigned *d_queue = nullptr;   /* two counters per kernel build: tickets taken, slabs handed back */
     unsigned *d_ptrmask = nullptr;
     bool      ptrmask_ready = false;
+    bool      no_coop = false, no_coop_done = false;        /* a frame's helper workgroups did not answer (FC_ERR_COOP): one workgroup per frame from here on */
     /* block-level speculation: workgroups per frame (0 = off), the descriptors of the verifier
      * workgroups, and one buffer with -- per frame -- control block + checkpoint slots, then the
      * verifiers' private tables */
@@ -1782,7 +1783,7 @@ static bool launch_wave(Staged *S)
                  * tables of a frame (frame_coder.h FcCoop).  One workgroup of 512 threads per CU; every workgroup
                  * of the launch must be resident: W x frames <= CUs, and nothing else launched beside it */
                 unsigned W = 1;
-                if (g == 3 && batch.size() == plain) {
+                if (g == 3 && batch.size() == plain && !S->no_coop) {
                     W = coop_policy(plain, S->ncu ? S->ncu : 256);
                     if (fa_knob("FIASCO_AMD_COOP") && atoi(fa_knob("FIASCO_AMD_COOP")) >= 1) {
                         W = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP"));
@@ -1790,6 +1791,7 @@ static bool launch_wave(Staged *S)
                         if ((size_t) W * ((plain + 7) / 8 * 8) > (size_t) (S->ncu ? S->ncu : 256)) W = 1;
                     }
                 }
+                if (S->no_coop) S->no_coop_done = true;
                 if (W > 1) {
                     static FcCoop zero[4];                 /* [d]: header of a frame with depth d */
                     unsigned D = 1;
@@ -1799,6 +1801,11 @@ static bool launch_wave(Staged *S)
                         D = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"));
                     memset(&zero[D], 0, sizeof zero[D]);
                     zero[D].depth = D;
+                    /* tests: FIASCO_AMD_COOP_WAIT_MS shortens the frame's wait, FIASCO_AMD_COOP_DEAF=1 sends the helpers
+                     * home at once (the frame then fails with FC_ERR_COOP and is searched again by one workgroup) */
+                    zero[D].done_ticks = fa_knob("FIASCO_AMD_COOP_WAIT_MS") ? 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_COOP_WAIT_MS"))
+                                                                            : FC_COOP_DONE_TICKS;
+                    zero[D].quit = fa_knob("FIASCO_AMD_COOP_DEAF") ? 1u : 0u;
                     zero[D].minsub = fa_knob("FIASCO_AMD_COOP_MINSUB") ? atoi(fa_knob("FIASCO_AMD_COOP_MINSUB")) : 1;
                     for (size_t b = at; b < at + plain && !fail; b++)
                         fail = hipMemcpyAsync(hf[b].coop, &zero[D], sizeof(FcCoop), hipMemcpyHostToDevice, S->stream) != hipSuccess;
@@ -1937,6 +1944,12 @@ static void complete_wave(Staged *S)
             if (fs.PA < fs.P) fs.PA = fs.P;
             if (fs.P > 12 * 1024) fs.spec = false;     /* beyond the speculating builds: one (wide) workgroup */
             if (!stage_slot(S, fs)) fs.done = true;
+            continue;
+        }
+        if (st == FC_ERR_COOP && !S->no_coop_done) {
+            /* the helper workgroups of the frame were not there in time (not resident: masked CUs, a busy device):
+             * the frame keeps its slab and is searched again by one workgroup -- a retry instead of a failure */
+            S->no_coop = true;
             continue;
         }
         if (st == FC_ERR_QUEUE && fs.borrow) {

@@ -64,6 +64,7 @@ struct FcCoop {
     int      level, from, to;
     int      minsub;         /* blocks whose subtrees have fewer than 2^minsub level-5 addresses are built the ordinary way */
     float   *ipis, *d5, *d4; /* the active table set (prediction swaps it) */
+    unsigned long long done_ticks;   /* how long the frame waits for its helpers (100 MHz wall clock; host) */
     /* the block's pixels (floats) follow at byte FC_COOP_HDR */
 };
 #define FC_COOP_HDR 128

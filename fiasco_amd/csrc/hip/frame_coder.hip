@@ -309,6 +309,7 @@ struct Sh {
 #if FC_VARIANT_BIG
     unsigned coopW, coop_seq;      /* workgroups of this frame (FcCoop), table builds published so far */
     int      coopD, coop_minsub;   /* FcCoop.depth / .minsub */
+    unsigned long long coop_ticks; /* FcCoop.done_ticks */
 #endif
     Pool     pool;
     CoeffBuf cb;
@@ -1029,7 +1030,7 @@ __device__ void coop_finish(DevFrame &__restrict__ F, Sh &__restrict__ sh, int l
     __syncthreads();
     if (tid == 0) {
         const unsigned want = sh.coop_seq * (W - 1);
-        const unsigned long long t_give_up = wall_clock64() + FC_COOP_DONE_TICKS;
+        const unsigned long long t_give_up = wall_clock64() + sh.coop_ticks;
         while (__hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             if (wall_clock64() > t_give_up) { sh.failed = FC_ERR_COOP; break; }
             __builtin_amdgcn_s_sleep(4);
@@ -3195,6 +3196,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     if (threadIdx.x == 0) {
         sh.coopW = F.coop ? cW : 1; sh.coop_seq = 0;
         sh.coopD = cW > 1 && F.coop ? (int) F.coop->depth : 0; sh.coop_minsub = cW > 1 && F.coop ? F.coop->minsub : 0;
+        sh.coop_ticks = cW > 1 && F.coop ? F.coop->done_ticks : 0;
     }
 #else
     DevFrame &F = frames[blockIdx.x];

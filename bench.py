@@ -215,6 +215,49 @@ def k4_pass(lib, nframes, rank):
             "limits": "MAXSTATES 30000, MAXLEVEL 26 (declared extension, SURVEY 8c)"}
 
 
+REF_MD5_CONFIG5_300 = "714a25c639d8daae598f84095f4856f7"     # the real reference's stream of these 300 inputs (68 min on one core)
+
+
+def config5_pass(lib, nframes):
+    """BASELINE config 5 on ONE GPU, driver-timed: `nframes` 1280x720 colour frames (SURVEY App. C k-generator, shifted
+    by 3 px per frame), pattern ippppppppp, --prediction, through fiasco_coder() -- PPM files read, 30 GOPs searched
+    side by side per frame position (big kernel build, 8 workgroups per frame for the table passes), every coded frame
+    decoded on the device for the next one, .fco written.  300 frames: the stream must be the real reference's."""
+    import multiprocessing as mp
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_config5
+    td = tempfile.mkdtemp()
+    tg = time.perf_counter()
+    with mp.get_context("fork").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        paths = pool.map(gpu_config5.make, [(f, os.path.join(td, "v%03d.ppm" % f)) for f in range(nframes)])
+    t_gen = time.perf_counter() - tg
+    lib.L.fiasco_amd_release_memory()
+    o = lib.cli_options()
+    o.set_prediction(1, 6, 10)
+    out = os.path.join(td, "dev.fco")
+    try:
+        lib.reset_stats()
+        t0 = time.perf_counter()
+        ok = lib.fiasco_coder(paths, out, 20.0, o) == 1
+        dt = time.perf_counter() - t0
+        st = lib.get_stats()
+        data = open(out, "rb").read() if ok else b""
+    finally:
+        o.delete()
+        lib.L.fiasco_amd_release_memory()
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
+    md5 = hashlib.md5(data).hexdigest() if ok else None
+    return {"workload": "%d frames 1280x720 colour, ippppppppp, --prediction, fiasco_coder() file to file" % nframes,
+            "all_encoded": ok, "seconds": dt, "frames_per_s": nframes / dt if ok else None, "bytes": len(data),
+            "kernel_seconds": st.kernel_ms / 1e3, "launches": int(st.launches), "reencoded_frames": int(st.reencodes),
+            "workgroups_per_frame_for_tables": int(st.coop_workgroups), "frames_decoded_on_device": int(st.decoder_frames),
+            "parity": (("stream md5 == the real reference's (%s)" % md5[:12]) if md5 == REF_MD5_CONFIG5_300 else "MISMATCH: %s" % md5)
+                      if nframes == 300 else "md5 %s (known answer exists for 300 frames only)" % md5,
+            "generate_seconds": t_gen}
+
+
 # ---- synthetic frames: one seed per frame (SURVEY Appendix C generator, tests/synth.py) ----
 
 _BASE = {}
@@ -275,6 +318,8 @@ def main():
                          "--width 3840 --height 2160 --frames-per-gpu 64 on 1/2/4/8 GPUs)")
     ap.add_argument("--k4-frames", type=int, default=256,
                     help="frames of the extra 3840x2160 pass (BASELINE config 4 on one GPU; 0 = skip)")
+    ap.add_argument("--config5-frames", type=int, default=300,
+                    help="frames of the extra 1280x720 colour video pass (BASELINE config 5 on one GPU; 0 = skip)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -433,9 +478,11 @@ def main():
             assert all(out2[j] == out[(j + k) % F] for j in range(0, F, max(1, F // 64))), \
                 "pipelined pass did not encode the uploaded frames"
         batch.free()
-        small = k4 = None
+        small = k4 = c5 = None
         if rank == 0 and world == 1 and a.k4_frames > 0 and (a.width, a.height) == (1920, 1080):
             k4 = k4_pass(lib, a.k4_frames, rank)
+        if rank == 0 and world == 1 and a.config5_frames > 0 and (a.width, a.height) == (1920, 1080):
+            c5 = config5_pass(lib, a.config5_frames)
         if rank == 0 and world == 1 and not a.no_small_launches and (a.width, a.height) == (1920, 1080):
             small = small_launches(lib, opt, uniq, a.width, a.height)
 
@@ -504,6 +551,8 @@ def main():
                        # target: >= 50 frames/s on one GPU)
                        "k4_frames_per_s": (k4 or {}).get("frames_per_s") if not dry else None,
                        "k4": k4 if not dry else None,
+                       # BASELINE config 5's workload on this GPU (north-star row F3/F4: motion search, prediction, decoder)
+                       "config5": c5 if not dry else None,
                        # launches that leave the chip empty: several workgroups per frame (speculation)
                        "small_launches": small if not dry else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

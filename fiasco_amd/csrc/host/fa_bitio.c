@@ -51,6 +51,26 @@ void fa_bw_align(fa_bitw *b)
 
 size_t fa_bw_finish(fa_bitw *b) { return b->bytes; }
 
+/* What `src` holds behind a byte-aligned `b` (bitpos 0, or nothing written yet): the cursor ends where the
+ * writes into src would have left it had they gone to b. */
+void fa_bw_append(fa_bitw *b, const fa_bitw *src)
+{
+    const int fresh = b->nbits == 0;                 /* byte 0 is touched but empty */
+    const size_t at = fresh ? 0 : b->bytes, need = at + src->bytes;
+    if (src->nbits == 0) return;
+    if (need > b->cap) {
+        size_t nc = b->cap;
+        unsigned char *nb;
+        while (nc < need) nc *= 2;
+        nb = (unsigned char *) realloc(b->buf, nc);
+        if (!nb) abort();
+        memset(nb + b->cap, 0, nc - b->cap);
+        b->buf = nb; b->cap = nc;
+    }
+    memcpy(b->buf + at, src->buf, src->bytes);
+    b->bytes = need; b->bitpos = src->bitpos; b->nbits += src->nbits;
+}
+
 void fa_bw_rice(fa_bitw *b, unsigned value, unsigned k)
 {
     unsigned u;

@@ -286,6 +286,7 @@ typedef struct fa_bitw {
 } fa_bitw;
 void fa_bw_init(fa_bitw *b);
 void fa_bw_free(fa_bitw *b);
+void fa_bw_append(fa_bitw *b, const fa_bitw *src);   /* b byte-aligned: what src holds, behind it */
 void fa_bw_put_bit(fa_bitw *b, unsigned v);
 void fa_bw_put_bits(fa_bitw *b, unsigned v, unsigned n);
 void fa_bw_align(fa_bitw *b);

@@ -431,6 +431,28 @@ int fa_seq_write(fa_seq *s, unsigned k, const uint8_t *ycol, fa_bitw *out)
                           s->op->delta_domains, out);
 }
 
+/* the streams of the frames `first, first + stride, ...', each into a writer of its own */
+#define WR_THREADS 16
+typedef struct wr_share {
+    fa_seq *s;
+    fa_bitw *fb;
+    uint8_t *ok;
+    char (*err)[160];
+    unsigned first, stride;
+} wr_share;
+static void *wr_frames_thread(void *arg)
+{
+    wr_share *w = (wr_share *) arg;
+    fa_seq *s = w->s;
+    unsigned k;
+    for (k = w->first; k < s->ncoded; k += w->stride) {
+        fa_bw_init(&w->fb[k]);
+        w->ok[k] = (uint8_t) (fa_seq_write(s, k, NULL, &w->fb[k]) != 0);
+        if (!w->ok[k]) snprintf(w->err[k], 160, "%s", fiasco_get_error_message());
+    }
+    return NULL;
+}
+
 /* Everything in one process: search with speculation until every GOP started from what its
  * predecessor left, then the streams in coding order.  Used by fiasco_coder(). */
 int fa_seq_encode_all(fa_seq *s, fa_bitw *out, void (*report)(const fa_wfa *, const fa_stats *, const fa_info *))
@@ -442,7 +464,9 @@ int fa_seq_encode_all(fa_seq *s, fa_bitw *out, void (*report)(const fa_wfa *, co
     if (!carry || !todo) { fa_set_error("Out of memory!"); goto out; }
     {
         unsigned guess;
+        double tp = seq_now();
         if (!fa_seq_probe(s, &guess)) goto out;
+        if (fa_knob("FIASCO_AMD_SEQ_TIMING")) fprintf(stderr, "fa_seq_encode_all: probe %.2f s (level %u -> %u)\n", seq_now() - tp, s->cp.lc_min_level, guess);
         for (g = 0; g < s->ngop; g++) { carry[g] = g ? guess : s->cp.lc_min_level; todo[g] = 1; }
     }
     for (pass = 0; ; pass++) {
@@ -465,11 +489,47 @@ int fa_seq_encode_all(fa_seq *s, fa_bitw *out, void (*report)(const fa_wfa *, co
         chain = (uint8_t *) calloc(s->cap2, 1);       /* calloc'ed in the reference (codec/wfalib.c:107) */
         if (!chain) { fa_set_error("Out of memory!"); goto out; }
     }
-    for (k = 0; k < s->ncoded; k++) {
-        if (s->color) fa_seq_ycol_resolve(chain, fa_seq_ycol_raw(s, k), s->cap2);
-        if (report) report(s->wfa[k], s->stats[k], &s->wi);
-        if (!fa_seq_write(s, k, chain, out)) goto out;
+    double tw = seq_now();
+    {
+        /* The streams of the frames side by side (the writer is a pure function of a finished automaton and the
+         * flags resolved above it), joined in coding order.  A frame ends byte-aligned -- the arithmetic coder of its
+         * last section is flushed (lib/arith.c:86-115) --, and then what a fresh writer produced for the next frame
+         * IS what the shared one would have appended.  Should a frame end inside a byte (no edges at all), the rest
+         * is written the sequential way. */
+        wr_share sh[WR_THREADS];
+        pthread_t th[WR_THREADS];
+        int started[WR_THREADS] = { 0 };
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        unsigned nt = ncpu > WR_THREADS ? WR_THREADS : ncpu < 1 ? 1 : (unsigned) ncpu, t;
+        fa_bitw *fb = (fa_bitw *) calloc(s->ncoded ? s->ncoded : 1, sizeof *fb);
+        uint8_t *okv = (uint8_t *) calloc(s->ncoded ? s->ncoded : 1, 1);
+        char (*errv)[160] = (char (*)[160]) calloc(s->ncoded ? s->ncoded : 1, 160);
+        int failed = 0;
+        if (!fb || !okv || !errv) { free(fb); free(okv); free(errv); fa_set_error("Out of memory!"); goto out; }
+        for (k = 0; k < s->ncoded; k++) {
+            if (!s->wfa[k]) { free(fb); free(okv); free(errv); fa_set_error("frame %d was not searched by this process", (int) k); goto out; }
+            if (s->color) {                     /* the flags of frame k: resolved in coding order, kept in the automaton */
+                fa_seq_ycol_resolve(chain, fa_seq_ycol_raw(s, k), s->cap2);
+                memcpy(s->wfa[k]->y_column, chain, (size_t) s->wfa[k]->cap * 2);
+            }
+            if (report) report(s->wfa[k], s->stats[k], &s->wi);
+        }
+        if (nt > s->ncoded) nt = s->ncoded ? s->ncoded : 1;
+        for (t = 0; t < nt; t++) { sh[t].s = s; sh[t].fb = fb; sh[t].ok = okv; sh[t].err = errv; sh[t].first = t; sh[t].stride = nt; }
+        for (t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, wr_frames_thread, &sh[t]) == 0;
+        wr_frames_thread(&sh[0]);
+        for (t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else wr_frames_thread(&sh[t]); }
+        for (k = 0; k < s->ncoded && !failed; k++) {
+            const int aligned = out->bitpos == 0 || out->nbits == 0;
+            if (!okv[k]) { fa_set_error("%s", errv[k]); failed = 1; break; }
+            if (aligned) fa_bw_append(out, &fb[k]);
+            else if (!fa_seq_write(s, k, NULL, out)) failed = 1;          /* (the flags are in the automaton already) */
+        }
+        for (k = 0; k < s->ncoded; k++) fa_bw_free(&fb[k]);
+        free(fb); free(okv); free(errv);
+        if (failed) goto out;
     }
+    if (fa_knob("FIASCO_AMD_SEQ_TIMING")) fprintf(stderr, "fa_seq_encode_all: writer %.2f s\n", seq_now() - tw);
     rc = 1;
 out:
     free(carry); free(todo); free(chain);

@@ -24,12 +24,19 @@ def main():
     o = lib.cli_options(); o.set_prediction(1, 6, 10)
     out = os.path.join(td, "dev.fco")
     res = {}
-    if n >= 3:                                   # SURVEY App. C known answer of the reference
+    if n >= 3 and not os.environ.get("CONFIG5_NO_CHECK"):                                   # SURVEY App. C known answer of the reference
         assert lib.fiasco_coder(paths[:3], out, 20.0, o) == 1, lib.error_message()
         res["v0[0-2] md5 == reference"] = hashlib.md5(open(out, "rb").read()).hexdigest() == "2528889c0453c4590289ad07d9fb87e3"
+    lib.reset_stats()
     t0 = time.time()
     assert lib.fiasco_coder(paths, out, 20.0, o) == 1, lib.error_message()
     dt = time.time() - t0
+    st = lib.get_stats()
+    # a step of the sweep lasts as long as its slowest frame: mean frame time x steps against the kernel time
+    res["kernel_seconds"] = st.kernel_ms / 1e3
+    res["launches"] = int(st.launches)
+    res["mean_frame_seconds"] = st.t_total / 1e8 / max(st.frames, 1)
+    res["frames_searched"] = int(st.frames)
     data = open(out, "rb").read()
     res.update({"workload": "%d frames 1280x720 colour, ippppppppp, --prediction" % n, "seconds": dt,
                 "frames_per_s": n / dt, "bytes": len(data), "md5": hashlib.md5(data).hexdigest()})

@@ -733,7 +733,8 @@ struct Staged {
     unsigned *d_queue = nullptr;   /* two counters per kernel build: tickets taken, slabs handed back */
     unsigned *d_ptrmask = nullptr;
     bool      ptrmask_ready = false;
-    bool      no_coop = false, no_coop_done = false;        /* a frame's helper workgroups did not answer (FC_ERR_COOP): one workgroup per frame from here on */
+    bool      no_coop = false, no_coop_done = false;
+    FcCoop    coop_hdr;               /* what a launch writes over the control blocks of its frames (source of async copies) */        /* a frame's helper workgroups did not answer (FC_ERR_COOP): one workgroup per frame from here on */
     /* block-level speculation: workgroups per frame (0 = off), the descriptors of the verifier
      * workgroups, and one buffer with -- per frame -- control block + checkpoint slots, then the
      * verifiers' private tables */
@@ -1793,22 +1794,22 @@ static bool launch_wave(Staged *S)
                 }
                 if (S->no_coop) S->no_coop_done = true;
                 if (W > 1) {
-                    static FcCoop zero[4];                 /* [d]: header of a frame with depth d */
                     unsigned D = 1;
                     while ((1u << D) < W) D++;
                     if (fa_knob("FIASCO_AMD_COOP_DEPTH") && atoi(fa_knob("FIASCO_AMD_COOP_DEPTH")) >= 1 && atoi(fa_knob("FIASCO_AMD_COOP_DEPTH")) <= 3
                         && (1 << atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"))) >= (int) W)
                         D = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP_DEPTH"));
-                    memset(&zero[D], 0, sizeof zero[D]);
-                    zero[D].depth = D;
+                    FcCoop &hdr = S->coop_hdr;
+                    memset(&hdr, 0, sizeof hdr);
+                    hdr.depth = D;
                     /* tests: FIASCO_AMD_COOP_WAIT_MS shortens the frame's wait, FIASCO_AMD_COOP_DEAF=1 sends the helpers
                      * home at once (the frame then fails with FC_ERR_COOP and is searched again by one workgroup) */
-                    zero[D].done_ticks = fa_knob("FIASCO_AMD_COOP_WAIT_MS") ? 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_COOP_WAIT_MS"))
+                    hdr.done_ticks = fa_knob("FIASCO_AMD_COOP_WAIT_MS") ? 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_COOP_WAIT_MS"))
                                                                             : FC_COOP_DONE_TICKS;
-                    zero[D].quit = fa_knob("FIASCO_AMD_COOP_DEAF") ? 1u : 0u;
-                    zero[D].minsub = fa_knob("FIASCO_AMD_COOP_MINSUB") ? atoi(fa_knob("FIASCO_AMD_COOP_MINSUB")) : 1;
+                    hdr.quit = fa_knob("FIASCO_AMD_COOP_DEAF") ? 1u : 0u;
+                    hdr.minsub = fa_knob("FIASCO_AMD_COOP_MINSUB") ? atoi(fa_knob("FIASCO_AMD_COOP_MINSUB")) : 1;
                     for (size_t b = at; b < at + plain && !fail; b++)
-                        fail = hipMemcpyAsync(hf[b].coop, &zero[D], sizeof(FcCoop), hipMemcpyHostToDevice, S->stream) != hipSuccess;
+                        fail = hipMemcpyAsync(hf[b].coop, &hdr, sizeof(FcCoop), hipMemcpyHostToDevice, S->stream) != hipSuccess;
                     g_stats.coop_frames += plain; g_stats.coop_workgroups = W;
                 }
                 launch[g](S->d_frames + at, (unsigned) plain, (unsigned) plain, nullptr, nullptr, nullptr, qwait, W, S->stream);

@@ -361,6 +361,22 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
                 gop_run *q = &run[who[b]];
                 if (!need[b]) continue;
                 q->reconst = djobs[b].out;
+                if (q->reconst && fa_knob("FIASCO_AMD_SEQ_RECONST_LOG")) {
+                    /* tests: one line per reconstructed frame (GOP, step, FNV-1a of its planes) -- the device decoder
+                     * against the host restatement on P and B frames */
+                    FILE *lf = fopen(fa_knob("FIASCO_AMD_SEQ_RECONST_LOG"), "a");
+                    if (lf) {
+                        unsigned long long h = 1469598103934665603ull;
+                        int band;
+                        for (band = 0; band < (s->color ? 3 : 1); band++) {
+                            const unsigned char *p8 = (const unsigned char *) q->reconst->pixels[band];
+                            size_t i, n8 = (size_t) q->reconst->width * q->reconst->height * 2;
+                            for (i = 0; i < n8; i++) { h ^= p8[i]; h *= 1099511628211ull; }
+                        }
+                        fprintf(lf, "%u %u %d %016llx\n", q->g, step, (int) s->type[s->gfirst[q->g] + step], h);
+                        fclose(lf);
+                    }
+                }
                 if (!q->reconst) {
                     snprintf(s->gerr[q->g], 160, "%s", djobs[b].errmsg[0] ? djobs[b].errmsg : "decoder failed");
                     s->gfail[q->g] = 1; q->dead = 1;

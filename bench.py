@@ -301,7 +301,7 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames-per-gpu", type=int, default=1024)   # 4 frames per CU x 256 CUs
     ap.add_argument("--width", type=int, default=1920)

@@ -1502,8 +1502,8 @@ static int collect(Staged *S, FrameSlot &fs, const char *pinned)
     if (ns > g_stats.states_max) g_stats.states_max = ns;
     cap_hint_put(job, F.ystates_out, F.states);
     if (fa_knob("FIASCO_AMD_CAP_TRACE"))
-        fprintf(stderr, "capacity: frame type %d used %d table states of %d, %d states of %d\n", job->frame_type, F.ystates_out,
-                fs.P, F.states, fs.PA);
+        fprintf(stderr, "capacity: frame type %d used %d table states of %d, %d states of %d; %.3f s on the device\n", job->frame_type,
+                F.ystates_out, fs.P, F.states, fs.PA, (double) F.t_total / 1e8);
     return 1;
 }
 

@@ -61,6 +61,12 @@ struct fa_seq {
     unsigned  *carry_used, *carry_out;    /* per GOP: minimum level it started from / left */
     uint8_t   *gdone, *gfail;
     char     (*gerr)[160];
+    /* the probe frame (fa_seq_probe) is the first frame of GOP 0 searched from the stream's own starting level:
+     * the sweep takes it over instead of searching it again (the slowest frame of its step: the other GOPs start
+     * from the ratcheted level) */
+    fa_wfa    *probe_wfa;
+    fa_stats   probe_stats[3];
+    unsigned   probe_out;
 };
 
 static int frame_type_of(unsigned display, const char *pattern, int *ok)
@@ -114,6 +120,7 @@ void fa_seq_free(fa_seq *s)
     unsigned k;
     if (!s) return;
     for (k = 0; s->wfa && k < s->ncoded; k++) fa_wfa_free(s->wfa[k]);
+    fa_wfa_free(s->probe_wfa);
     free(s->wfa); free(s->stats); free(s->order); free(s->type); free(s->isfut); free(s->gfirst);
     free(s->carry_used); free(s->carry_out); free(s->gdone); free(s->gfail); free(s->gerr);
     fa_info_free(&s->wi);
@@ -255,7 +262,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
     }
     for (step = 0; step < maxlen; step++) {
         t0 = seq_now();
-        unsigned nb = 0, b;
+        unsigned nb = 0, b, predone = 0;
         /* the inputs of this step: PNM -> planes of every GOP's frame side by side on the host's cores */
         {
             parse_share sh[PARSE_THREADS];
@@ -297,6 +304,17 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             jobs[nb].image = ims[nb];
             jobs[nb].cp = s->cp;
             jobs[nb].cp.lc_min_level = q->carry;
+            if (nb == 0 && step == 0 && q->g == 0 && s->probe_wfa && q->carry == s->cp.lc_min_level && type == FA_I_FRAME) {
+                /* the probe was this very search: its result stands in for the job (entry 0, not sent to the core) */
+                jobs[nb].frame_type = type;
+                jobs[nb].wfa = s->probe_wfa; s->probe_wfa = NULL;
+                memcpy(jobs[nb].stats, s->probe_stats, sizeof jobs[nb].stats);
+                jobs[nb].lc_min_level_out = s->probe_out;
+                jobs[nb].status = 1;
+                predone = 1;
+                who[nb++] = r;
+                continue;
+            }
             jobs[nb].frame_type = type; jobs[nb].past = q->past; jobs[nb].future = q->future;
             jobs[nb].wfa = fa_wfa_alloc(s->cp.limit_states);
             if (!jobs[nb].wfa) {
@@ -322,7 +340,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
         }
         if (!nb) continue;
         t_prep += seq_now() - t0; t0 = seq_now();
-        (void) fa_core_encode_frames(nb, jobs);
+        if (nb > predone) (void) fa_core_encode_frames(nb - predone, jobs + predone);
         t_core += seq_now() - t0; t0 = seq_now();
         for (b = 0; b < nb; b++) {
             gop_run *q = &run[who[b]];
@@ -416,9 +434,19 @@ int fa_seq_probe(fa_seq *s, unsigned *level)
     memset(&job, 0, sizeof job);
     job.image = im; job.cp = s->cp; job.frame_type = FA_I_FRAME;
     job.wfa = fa_wfa_alloc(s->cp.limit_states);
-    ok = job.wfa && fa_load_basis(s->op->basis_name, job.wfa) && job.wfa->states < s->cp.limit_states
-         && fa_core_encode_frames(1, &job) == 1;
-    if (ok) *level = job.lc_min_level_out;
+    ok = job.wfa && fa_load_basis(s->op->basis_name, job.wfa) && job.wfa->states < s->cp.limit_states;
+    if (ok) {                                  /* exactly the job the sweep makes of this frame (fa_seq_search) */
+        memset(job.wfa->y_column, YCOL_UNSET, (size_t) job.wfa->cap * 2);
+        job.ycol_carry = 1;
+        ok = fa_core_encode_frames(1, &job) == 1;
+    }
+    fa_wfa_free(s->probe_wfa); s->probe_wfa = NULL;
+    if (ok) {
+        *level = job.lc_min_level_out;
+        s->probe_wfa = job.wfa; job.wfa = NULL;
+        memcpy(s->probe_stats, job.stats, sizeof job.stats);
+        s->probe_out = job.lc_min_level_out;
+    }
     fa_wfa_free(job.wfa); fa_image_free(im);
     return 1;                                  /* a failing first frame shows up in the sweep */
 }

@@ -146,6 +146,14 @@
 #else
 #define D5_AT(P, NA, a, s) ((unsigned) (a) * (unsigned) (P) + (unsigned) (s))
 #endif
+/* FC_PRIO_ROTATE: rotating instruction priority of the frames that share a CU (kernel loop); the 256-thread default
+ * build, whose launches put four workgroups on a CU */
+#ifndef FC_PRIO_ROTATE
+#define FC_PRIO_ROTATE (!FC_VARIANT_BIG && !FC_VARIANT_WIDE && !FC_SPEC)
+#endif
+#ifndef FC_PRIO_SHIFT
+#define FC_PRIO_SHIFT 20            /* 2^20 ticks of the 100 MHz wall clock: 10 ms per turn (82 us .. 42 ms measured: 580 .. 589 frames/s) */
+#endif
 #ifndef FC_SPINE
 #define FC_SPINE 0
 #endif
@@ -3521,6 +3529,21 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         const int op = sh.op;
         if (op == OP_DONE) break;
         unsigned long long t0 = wall_clock64();
+#if FC_PRIO_ROTATE
+        {
+            /* Four frames share a CU, one wave of each per SIMD, and the instruction arbiter takes the OLDEST ready
+             * wave: the frame whose workgroup arrived first ran 18 % faster than the one that arrived last (1.52 /
+             * 1.61 / 1.70 / 1.79 s by block id / 256), and a launch lasts as long as its slowest frame.  The user
+             * priority (s_setprio, above age in the arbitration) of the co-resident frames rotates with the wall
+             * clock -- every frame is first, second, third and last a quarter of the time -- so that they finish
+             * together.  What a frame computes does not depend on when its instructions issue. */
+            const unsigned pr = ((unsigned) (t0 >> FC_PRIO_SHIFT) + (blockIdx.x >> 8)) & 3u;       /* wave uniform */
+            if (pr == 0) __builtin_amdgcn_s_setprio(0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         switch (op) {
 #if FC_SPEC
         case OP_SPEC_CKPT: {

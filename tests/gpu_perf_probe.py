@@ -18,6 +18,8 @@ lib.set_verbosity(0)
 if max(w, h) > 2048:
     lib.set_limits(30000, 26)
 opt = lib.cli_options()
+if os.environ.get("PROBE_PRED"):            # intra prediction: the big kernel builds (256 threads, two frames per CU, for full launches)
+    opt.set_prediction(1, 6, 10)
 if os.environ.get("PROBE_COLOR"):          # colour frames (Y, Cb, Cr bands): SURVEY Appendix C k-generator
     if max(w, h) > 1280:
         lib.set_limits(30000, 26)              # 1080p colour needs the limits extension

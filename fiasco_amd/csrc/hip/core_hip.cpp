@@ -83,9 +83,27 @@ extern "C" unsigned fc_spec_slot_bytes_wide(void);
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
  * the CLI's -z 0 geometry, the big one block levels 4..12, up to 5 vectors and the
  * second-domain retry */
+/* A basis the rows inside DevFrame cannot hold: more than FC_MAXBASIS states, or a label with more than
+ * MAXEDGES edges (data/medium.fco, large.fco: the reference's append_edge runs on into the next row,
+ * fa_wfa_append_edge).  It travels as the memory image of its rows (DevFrame.bx); big kernel builds only. */
+static bool long_basis(const fa_wfa *w)
+{
+    if (!w) return false;
+    if (w->basis_states > FC_MAXBASIS) return true;
+    for (unsigned s = 0; s < w->basis_states; s++)
+        for (unsigned l = 0; l < 2; l++) {
+            unsigned e = 0;
+            while (e < 6 && FA_INTO(w, s, l, e) != FA_NO_EDGE) e++;
+            if (e > FA_MAXEDGES) return true;
+        }
+    return false;
+}
+static size_t bx_bytes(const fa_wfa *w) { return 16 + (size_t) w->basis_states * 80 + 72; }
+
 static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
 {
     if (cp->prediction) return true;         /* second model set, residual search: big build only */
+    if (long_basis(basis)) return true;
     /* the default build reads 3 edge slots per label (frame_coder.hip FC_MAXE): a basis file
      * whose states have more goes to the big build */
     if (basis)
@@ -530,6 +548,7 @@ struct Layout {
     size_t ipis_alt, d5_alt, d4_alt, pix_save, sv_gram, sv_img, sv_auto;   /* prediction only */
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
     size_t coop;                                                            /* FcCoop: header + the block's pixels */
+    size_t bx;                                                              /* DevFrame.bx: rows of a long basis */
     int    max_save;
 };
 
@@ -593,6 +612,7 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(mc_bwd, inter ? (size_t) plevels * 1024 * 4 : 0);
     CARVE(pix_chroma, inter && color ? npix / 3 * 2 * 2 : 0);
     CARVE(coop, FC_COOP_HDR + ((size_t) (NS + 1) << il) * 4);
+    CARVE(bx, FC_BX_BYTES);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -635,7 +655,17 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         snprintf(why, n, "RPF mantissa > 5 bits is not supported by the device coder yet");
         return 0;
     }
-    if (job->wfa->basis_states > FC_MAXBASIS) { snprintf(why, n, "initial basis too large for the device coder"); return 0; }
+    if (long_basis(job->wfa)) {
+        const fa_wfa *w = job->wfa;
+        if (bx_bytes(w) > FC_BX_BYTES) { snprintf(why, n, "initial basis too large for the device coder"); return 0; }
+        /* every edge list must end inside the rows of the basis (the device takes a copy of those rows; a list that
+         * ran on into the rows of the coder's own states would change while the frame is coded) */
+        for (unsigned r = 0; r < w->basis_states * 2; r++) {
+            unsigned e = r * 6;
+            while (e < w->basis_states * 12 && w->into[e] != FA_NO_EDGE) e++;
+            if (e >= w->basis_states * 12) { snprintf(why, n, "edge lists of the initial basis run on into the coder's states"); return 0; }
+        }
+    }
     /* the models fiasco.h can ask for -- and only those -- run on the device: `rle' pools, `adaptive'
      * coefficients (the `constant' pool is the delta pool of a plain I frame and is never searched).  The
      * others of the reference's registries exist in the CPU oracle only (no setter in fiasco.h reaches them,
@@ -670,6 +700,7 @@ struct FrameSlot {
     bool     spec = false;       /* several workgroups per frame (FC_SPEC build): the slab's capacity holds the
                                   * verifiers' state-id ranges */
     std::vector<uint8_t> ycol_host;      /* upload source of ycol0, alive until the slot goes */
+    std::vector<int32_t> bx_host;        /* ... of DevFrame.bx */
     const int16_t *ext_pix = nullptr;    /* pixel planes outside the slab (fa_core_upload_commit) */
     const int16_t *ext_next = nullptr;   /* ... of the frames the NEXT pass encodes */
     /* the host image this pass encodes, as of its submit: fiasco_amd_batch_upload() may point
@@ -845,9 +876,10 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.price = cp->price;
     F.lc_min = (int) cp->lc_min_level; F.lc_max = (int) cp->lc_max_level;
     F.images_level = (int) cp->images_level; F.max_elements = (int) cp->max_elements;
+    const bool bxl = long_basis(w);
     {
         unsigned live = cp->max_elements;
-        for (unsigned st = 0; st < w->basis_states; st++)
+        for (unsigned st = 0; st < (bxl ? 0u : w->basis_states); st++)
             for (unsigned l = 0; l < 2; l++) {
                 unsigned e = 0;
                 while (e < 6 && FA_INTO(w, st, l, e) != FA_NO_EDGE) e++;
@@ -879,7 +911,8 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.coeff_size = (F.lc_max - F.lc_min + 1) * F.sy + F.dcs;
     F.coeff_nt = F.lc_max - F.lc_min + 2;
     F.basis_states = (int) w->basis_states;
-    for (unsigned s = 0; s < w->basis_states; s++) {
+    F.bx = bxl ? (const int *) (base + L.bx) : nullptr;
+    for (unsigned s = 0; s < (bxl ? 0u : w->basis_states); s++) {
         F.b_final[s] = w->final_distribution[s];
         F.b_dtype[s] = w->domain_type[s];
         for (int l = 0; l < 2; l++) {
@@ -967,7 +1000,7 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
     /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
-    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !fa_knob("FIASCO_AMD_NO_QUEUE");
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !long_basis(job->wfa) && !fa_knob("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
@@ -1095,6 +1128,23 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         if (hipMemcpyAsync(fs.base + fs.L.ycol0, fs.ycol_host.data(), fs.ycol_host.size(),
                            hipMemcpyHostToDevice, S->stream) != hipSuccess) {
             snprintf(job->errmsg, sizeof job->errmsg, "HIP error: y_column upload failed");
+            slab_release(fs.base, fs.bytes); fs.base = nullptr;
+            return 0;
+        }
+    }
+    if (fs.F.bx) {                         /* the rows of a long basis, as they lie in the host's memory (DevFrame.bx) */
+        const fa_wfa *w = job->wfa;
+        const unsigned nb = w->basis_states, nr = 12 * nb + 12;
+        fs.bx_host.assign((bx_bytes(w) + 3) / 4, 0);
+        int32_t *b = fs.bx_host.data();
+        b[0] = (int32_t) nb; b[1] = (int32_t) nr;
+        memcpy(b + 4, w->final_distribution, (size_t) nb * 4);
+        for (unsigned s = 0; s < nb; s++) b[4 + nb + s] = w->domain_type[s];
+        float *bw = (float *) (b + 4 + 2 * nb);
+        int16_t *bi = (int16_t *) (b + 4 + 2 * nb + nr);
+        for (unsigned k = 0; k < nr; k++) { bi[k] = k < 12 * nb ? w->into[k] : (int16_t) FA_NO_EDGE; bw[k] = k < 12 * nb ? w->weight[k] : 0.0f; }
+        if (hipMemcpyAsync(fs.base + fs.L.bx, b, fs.bx_host.size() * 4, hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: basis upload failed");
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
             return 0;
         }
@@ -1784,7 +1834,9 @@ static bool launch_wave(Staged *S)
                  * tables of a frame (frame_coder.h FcCoop).  One workgroup of 512 threads per CU; every workgroup
                  * of the launch must be resident: W x frames <= CUs, and nothing else launched beside it */
                 unsigned W = 1;
-                if (g == 3 && batch.size() == plain && !S->no_coop) {
+                bool any_bx = false;                /* a long basis: its table rows are built by the frame's own workgroup */
+                for (size_t b = at; b < at + plain; b++) any_bx = any_bx || hf[b].bx != nullptr;
+                if (g == 3 && batch.size() == plain && !S->no_coop && !any_bx) {
                     W = coop_policy(plain, S->ncu ? S->ncu : 256);
                     if (fa_knob("FIASCO_AMD_COOP") && atoi(fa_knob("FIASCO_AMD_COOP")) >= 1) {
                         W = (unsigned) atoi(fa_knob("FIASCO_AMD_COOP"));

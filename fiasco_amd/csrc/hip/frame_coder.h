@@ -43,7 +43,8 @@
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */
 #define FC_MAXCOEFF_BIG 640     /* big build: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
 #define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
-#define FC_MAXBASIS 16          /* states of the initial basis */
+#define FC_MAXBASIS 16          /* states of an initial basis that travels inside DevFrame (else DevFrame.bx) */
+#define FC_BX_BYTES (64 * 1024)  /* room for DevFrame.bx in a slab: 2700 basis states */
 #define FC_TRI_HOT  8           /* states whose Gram columns the triangular layout also keeps as rows (DevFrame.gcol) */
 
 enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5,
@@ -103,6 +104,15 @@ typedef struct DevFrame {
     float    b_weight[FC_MAXBASIS][2][6];
     float    b_final[FC_MAXBASIS];
     uint8_t  b_dtype[FC_MAXBASIS];
+    /* ---- or, for a basis that does not fit the rows above (more than FC_MAXBASIS states, or labels with more than
+     * MAXEDGES edges: data/medium.fco, data/large.fco), the reference's own memory image of the basis rows.  The
+     * reference never checks MAXEDGES (codec/wfalib.c:253-273): the rows into[state][label][MAXEDGES + 1] lie back
+     * to back in one block (codec/wfa.h:131-133, codec/wfalib.c:70-75), a label's sixth and later edges run on into
+     * the row of the next label, every reader walks a list up to the first NO_EDGE -- so the edge list of (state,
+     * label) is into[(2 state + label) * 6 ..] up to the terminator, up to 33 entries in large.fco.  Big kernel
+     * builds only.  Words: [0] basis states nb, [1] row entries n = 12 nb + 12, [2..3] 0; float final[nb];
+     * int domain_type[nb]; float weight[n]; int16 into[n].  null: the basis is in b_tree .. b_dtype. ---- */
+    const int *bx;
     /* ---- tables ---- */
     const int16_t *pix16;
     float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;

@@ -709,6 +709,53 @@ __device__ float image_elem(const DevFrame &F, int s, int l, int i)
     return v;
 }
 
+#if FC_VARIANT_BIG
+/* ---- a basis that travels as the memory image of its rows (DevFrame.bx; data/medium.fco, large.fco) ----
+ * The edge list of (state, label) starts at entry (2 state + label) * 6 and ends at the first NO_EDGE -- beyond
+ * the row's own six entries where the reference's append_edge ran on into the next row (codec/wfalib.c:253-273).
+ * Basis states have no tree children.  Their rows in the automaton arrays of the slab stay empty: the table
+ * passes below take the basis states' terms from here, in the reference's order of additions. */
+struct BxView { int nb; const float *final_d; const int *dtype; const float *w; const int16_t *into; };
+__device__ __forceinline__ BxView bx_view(const DevFrame &F)
+{
+    BxView v;
+    const int *b = F.bx;
+    v.nb = b[0];
+    v.final_d = (const float *) (b + 4); v.dtype = b + 4 + v.nb; v.w = (const float *) (b + 4 + 2 * v.nb);
+    v.into = (const int16_t *) (b + 4 + 2 * v.nb + b[1]);
+    return v;
+}
+
+/* image_elem() of a basis state */
+__device__ float image_elem_bx(const DevFrame &F, const BxView &V, int s, int l, int i)
+{
+    const int half = 1 << (l - 1), label = i >= half, pos = i - label * half, base = half - 1;
+    float v = 0;
+    int dom;
+    for (int e = (s * 2 + label) * 6; (dom = V.into[e]) != NOEDGE; e++)
+        v += F.img[(size_t) dom * F.NI + base + pos] * V.w[e];
+    return v;
+}
+
+/* gram_entry() of two basis states */
+__device__ float gram_entry_bx(const DevFrame &F, const BxView &V, int q, int s1, int s2)
+{
+    const float *G = GRAM(F, q - 1);
+    const int P = F.P;
+    float ip = 0;
+    for (int label = 0; label < 2; label++) {
+        int d1, d2;
+        for (int e1 = (s1 * 2 + label) * 6; (d1 = V.into[e1]) != NOEDGE; e1++) {
+            float sum = 0;
+            for (int e2 = (s2 * 2 + label) * 6; (d2 = V.into[e2]) != NOEDGE; e2++)
+                sum += V.w[e2] * gram_load(G, P, d1, d2, NOFLIM);
+            ip += V.w[e1] * sum;
+        }
+    }
+    return ip;
+}
+#endif
+
 /* ------------------------------------------------------------------ parallel ops */
 
 /* <sub-block, state> tables in use: the block's, or -- big build, while the residual of a
@@ -804,9 +851,26 @@ template <int E> __device__ __noinline__ void op_ipis_t(const DevFrame &__restri
         GLOBAL_AS const float *src0 = (lv == il + 1) ? d5 + (size_t) (adr0 * 2) * P
                                                      : ipis + (size_t) (slot0 * 2 + 1) * P;
 #endif
+        int s = from + tid;
+#if FC_VARIANT_BIG
+        if (F.bx) {                        /* basis states with their terms in DevFrame.bx (see bx_view) */
+            const BxView V = bx_view(F);
+            for (int i = tid; i < V.nb * cnt; i += B) {
+                const int bs = i / cnt, j = i - bs * cnt;
+                if (bs < from || !V.dtype[bs]) continue;
+                float acc = 0;
+                for (int l = 0; l < 2; l++) {
+                    int dom;
+                    for (int e = (bs * 2 + l) * 6; (dom = V.into[e]) != NOEDGE; e++)
+                        acc += V.w[e] * ldg(src0, (unsigned) dom + (unsigned) ((j * 2 + l) * P));
+                }
+                stg(ipis, (unsigned) bs + (unsigned) ((slot0 + j) * P), acc);
+            }
+            if (from < V.nb) s = V.nb + tid;
+        }
+#endif
         /* the rows of the NEXT state of this lane are requested before the gathers of the
          * current one are waited for (one memory round trip per state instead of two) */
-        int s = from + tid;
         EdgeRowsT<E> nx;
         if (s < states) load_edge_rows(T, s, nx);
         for (; s < states; s += B) {
@@ -1314,6 +1378,27 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
 #endif
             }
             for (int q = q1; q < F.NL; q++) {
+#if FC_VARIANT_BIG
+                if (F.bx && t < F.basis_states) {      /* the terms of a basis state: DevFrame.bx */
+                    const BxView V = bx_view(F);
+                    GLOBAL_AS const float *Gb = gram + (size_t) (q - 1) * LS;
+                    float ipb = 0;
+                    for (int l = 0; l < 2; l++) {
+                        const int na = sh.gs_n[l], ca = sh.gs_c[l];
+                        for (int a = 0; a < na; a++) {
+                            const int A = sh.gs_idx[l][a];
+                            float sum = 0;
+                            int d2;
+                            for (int e2 = (t * 2 + l) * 6; (d2 = V.into[e2]) != NOEDGE; e2++)
+                                sum += V.w[e2] * ldg(Gb, gram_idx(Pu, A, d2, flim));
+                            if (a == 0 && ca) ipb += sum;
+                            else ipb += sh.gs_w[l][a] * sum;
+                        }
+                    }
+                    stg(gram, (unsigned) q * LS + rs + (unsigned) t, ipb);
+                    continue;
+                }
+#endif
                 /* codec/ip.c:213-257: ip = sum_label sum_{a in terms(s)} [w_a *] ( sum_{b in
                  * terms(t)} [w_b *] G_{q-1}[a][b] ); a tree child enters without a multiply.
                  * All gathers of a label (terms(s) x 6 slots of t) are issued before the first
@@ -3152,6 +3237,44 @@ __device__ void basis_init(DevFrame &F, Sh &sh)
     sh.states = nb;
 }
 
+#if FC_VARIANT_BIG
+/* the same for a basis in DevFrame.bx (hundreds of states with edge lists of up to 33 entries): all lanes; a level
+ * of the images / of the Gram tables needs the level below complete for ALL basis states (codec/control.c:205-258,
+ * codec/ip.c:213-257) */
+__device__ void basis_init_bx(DevFrame &F, Sh &sh)
+{
+    const int tid = threadIdx.x, il = F.images_level;
+    const BxView V = bx_view(F);
+    const int nb = V.nb;
+    for (int s = tid; s < nb; s += B) {
+        F.img[(size_t) s * F.NI] = F.final_d[s];
+        if (il == 0) F.imgT[s] = F.final_d[s];
+    }
+    __syncthreads();
+    for (int l = 1; l <= il; l++) {
+        for (int k = tid; k < (nb << l); k += B) {
+            const int s = k >> l, i = k & ((1 << l) - 1);
+            const float v = image_elem_bx(F, V, s, l, i);
+            F.img[(size_t) s * F.NI + (1 << l) - 1 + i] = v;
+            if (l == il) F.imgT[(size_t) i * F.P + s] = v;
+            if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) i * F.P + s] = v;
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < F.NL; q++) {
+        for (int k = tid; k < nb * nb; k += B) {
+            const int s1 = k / nb, s2 = k - s1 * nb;
+            if (s2 > s1 || !F.domain_type[s2]) continue;
+            float v;
+            if (F.gl0 < il) v = q == 0 ? gram_dot4(F, s1, s2) : q == 1 ? gram_dot(F, s1, s2) : gram_entry_bx(F, V, q, s1, s2);
+            else v = q == 0 ? gram_dot(F, s1, s2) : gram_entry_bx(F, V, q, s1, s2);
+            gram_store(F, q, s1, s2, v);
+        }
+        __syncthreads();
+    }
+}
+#endif
+
 /*
  *  One workgroup per frame.  A launch may hold more frames than slabs (more than the chip runs at
  *  once, or than HBM holds): the first `nlend` frames own a slab each, the others borrow one --
@@ -3312,6 +3435,17 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         }
 #endif
         /* rows of the basis states (input/basis.c:61-114, input/read.c:219-340) */
+#if FC_VARIANT_BIG
+        if (F.bx) {                          /* their edges stay in DevFrame.bx (bx_view) */
+            const BxView V = bx_view(F);
+            for (int s = 0; s < V.nb; s++) {
+                F.final_d[s] = V.final_d[s];
+                F.domain_type[s] = (uint8_t) V.dtype[s];
+                F.level_of_state[s] = 0xff;
+                for (int l = 0; l < 2; l++) { TREE(F, s, l) = RANGE_; INTO(F, s, l, 0) = NOEDGE; }
+            }
+        } else
+#endif
         for (int s = 0; s < F.basis_states; s++) {
             F.final_d[s] = F.b_final[s];
             F.domain_type[s] = F.b_dtype[s];
@@ -3405,6 +3539,12 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.dq.rpf_range = F.d_rpf_range; sh.dq.dc_range = F.d_dc_range;
         if (F.pred_on && F.d_coeff_size > FC_MAXCOEFF_BIG) sh.failed = FC_ERR_INTERNAL;
 #endif
+#if FC_VARIANT_BIG
+        if (F.bx) sh.states = F.basis_states;        /* tables: basis_init_bx below, all lanes */
+        else
+#else
+        if (F.bx) sh.failed = FC_ERR_INTERNAL;       /* a long basis needs a big build (core_hip.cpp routes) */
+#endif
         basis_init(F, sh);
         /* root range (codec/coder.c:738-745) */
         sh.flim = 0;
@@ -3428,6 +3568,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     }
     if (F.color)                              /* calloc'ed in the reference (codec/wfa.h) */
         for (int i = tid; i < 2 * F.PA; i += B) F.ycol[i] = F.ycol0 ? F.ycol0[i] : (uint8_t) 0;
+#if FC_VARIANT_BIG
+    if (F.bx) { __syncthreads(); basis_init_bx(F, sh); }
+#endif
 #if FC_SPEC
     }
 #endif

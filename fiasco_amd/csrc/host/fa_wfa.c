@@ -79,7 +79,13 @@ int fa_wfa_append_edge(fa_wfa *w, unsigned from, unsigned into, float weight, un
         pos++;
     for (last = pos; FA_INTO(w, from, label, last) != FA_NO_EDGE; last++)
         ;
-    if (last >= FA_MAXEDGES) return 0;          /* the row holds MAXEDGES edges + the terminator */
+    /* The reference does not check MAXEDGES (codec/wfalib.c:253-273): rows lie back to back in one block,
+     * into[state][label][MAXEDGES + 1] (codec/wfa.h:131-133, codec/wfalib.c:70-75), so the sixth and later
+     * edges of a label run on into the row of the next label (or state), whose own edges are then sorted in
+     * among them.  The bases medium.fco / large.fco rely on it (up to 8 edges per label in the file, lists of
+     * up to 33 entries in memory); every reader walks a list up to the first NO_EDGE, so the result is well
+     * defined.  Only the end of the block is a limit. */
+    if ((from * 2 + label) * 6 + (unsigned) last + 2 > w->cap * 12) return 0;
     for (e = last + 1; e > pos; e--) {          /* shift tail incl. the terminator */
         FA_INTO(w, from, label, e)   = FA_INTO(w, from, label, e - 1);
         FA_WEIGHT(w, from, label, e) = FA_WEIGHT(w, from, label, e - 1);

@@ -7,6 +7,7 @@
 #     oracle/_ref/cfiasco_ref        reference CLI     (bin/cwfa.c + params + getopt)
 #     oracle/_ref/dfiasco_ref        reference decoder CLI (bin/dwfa.c) and
 #     oracle/_ref/pnmpsnr_ref        PSNR tool (bin/pnmpsnr.c): decoded-PSNR known answers
+#     oracle/_ref/share/             the reference's installed data files (data/*.fco, the initial bases)
 #     oracle/_ref/libfiasco_ref_big.so / cfiasco_ref_big
 #                                    "limits extension" variant: MAXSTATES 6000 -> 30000,
 #                                    MAXLEVEL 22 -> 26, init_tree_model() uses entry 21 of its two count
@@ -91,6 +92,12 @@ gcc $CFLAGS -I"$REF/bin" -c "$REF/bin/pnmpsnr.c" -o "$OUT/obj/bin_pnmpsnr.o"
 gcc -fcommon -o "$OUT/dfiasco_ref" "$OUT/obj/bin_dwfa.o" "$OUT/obj/bin_params.o" "$OUT/obj/bin_binerror.o" \
     "$OUT/obj/bin_getopt.o" "$OUT/obj/bin_getopt1.o" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
 gcc -fcommon -o "$OUT/pnmpsnr_ref" "$OUT/obj/bin_pnmpsnr.o" "$OUT/obj/bin_binerror.o" -L"$OUT" -lfiasco_ref -Wl,-rpath,'$ORIGIN' -lm
+# the reference's run-time data (what `make install' puts into $(pkgdatadir): the ASCII initial bases small /
+# medium / large .fco that --basis-name names): installed beside the binaries so that the checker can be run
+# with them where /root/reference does not exist (FIASCO_DATA=oracle/_ref/share); like everything under
+# oracle/_ref/ they are build output, git-ignored, never part of the product
+mkdir -p "$OUT/share"
+cp "$REF"/data/*.fco "$OUT/share/"
 echo "ref_build: built $OUT/libfiasco_ref.so, $OUT/cfiasco_ref, dfiasco_ref and pnmpsnr_ref"
 
 # ---- the other entries of the reference's model registries (codec/domain-pool.c:188-236, codec/coeff.c:97-131)

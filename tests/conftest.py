@@ -21,6 +21,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle_fiasco.so")
+# where --basis-name looks (open_file(): cwd, then the FIASCO_DATA list): our own long bases
+# (tests/golden/long_*.fco) and the reference's installed data files (oracle/_ref/share, oracle/ref_build.sh)
+REF_SHARE = os.path.join(ROOT, "oracle", "_ref", "share")
+os.environ.setdefault("FIASCO_DATA", GOLDEN + ":" + REF_SHARE)
 
 
 def pytest_configure(config):
@@ -147,6 +151,7 @@ def options_from_args(lib, args):
         elif a == "--chroma-dictionary": kw["chroma_dictionary"] = int(v)
         elif a == "--tiling-exponent": kw["tiling_exponent"] = int(v)
         elif a == "--tiling-method": kw["tiling_method"] = v
+        elif a == "--basis-name": kw["basis_name"] = v
         else: raise ValueError(a)
         i += 2
     o = lib.cli_options(optimize=optimize, dictionary_size=dict_size, **kw)
@@ -157,7 +162,14 @@ def options_from_args(lib, args):
     o.set_quantization(rpf["m"], rng(rpf["r"]), rpf["dm"], rng(rpf["dr"]))
     if title: o.set_title(title)
     if comment: o.set_comment(comment)
+    if "basis_name" in kw: o.set_basisfile(kw["basis_name"].encode())
     return quality, o
+
+
+def option_cases(manifest):
+    """The "option_cases" of the manifest (tests/golden/make_options.py) that can run here: the ones with the
+    reference's own medium.fco / large.fco need oracle/_ref/share."""
+    return [c for c in manifest["option_cases"] if c.get("needs") != "share" or os.path.exists(os.path.join(REF_SHARE, "medium.fco"))]
 
 
 def encode_case(lib, case, inputs, outdir):

@@ -71,6 +71,9 @@ extern "C" void fc_launch_wide_tri(DevFrame *d_frames, unsigned n, unsigned nlen
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
+/* the 512-thread big build with coefficient models of up to 512 symbols per context (frame_coder.h FC_HM) */
+extern "C" void fc_launch_big_hm(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 
 /* block-level speculation (frame_coder.h, FcSpecCtl): n frames with G workgroups each */
 extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
@@ -100,8 +103,15 @@ static bool long_basis(const fa_wfa *w)
 }
 static size_t bx_bytes(const fa_wfa *w) { return 16 + (size_t) w->basis_states * 80 + 72; }
 
+/* RPF mantissas of more than 5 bits (cfiasco --rpf-mantissa / --dc-rpf-mantissa 6 .. 8): the FC_HM build */
+static bool needs_hm_variant(const fa_cparams *cp)
+{
+    return cp->rpf.mantissa_bits > 5 || cp->dc_rpf.mantissa_bits > 5 || cp->d_rpf.mantissa_bits > 5 || cp->d_dc_rpf.mantissa_bits > 5;
+}
+
 static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
 {
+    if (needs_hm_variant(cp)) return true;
     if (cp->prediction) return true;         /* second model set, residual search: big build only */
     if (long_basis(basis)) return true;
     /* the default build reads 3 edge slots per label (frame_coder.hip FC_MAXE): a basis file
@@ -555,7 +565,7 @@ struct Layout {
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
 static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix,
-                          int max_save, int inter, int plevels, int color, bool tri)
+                          int max_save, int inter, int plevels, int color, bool tri, bool hm)
 {
     Layout L;
     memset(&L, 0, sizeof L);             /* compared with memcmp (frame queue) */
@@ -595,8 +605,9 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(ycol0, (size_t) 2 * PA);                   /* initial y_column flags (colour streams) */
     /* model snapshots of the big build: aac [depth][slots][n16] x 16 bytes, with prediction 5
      * slots per depth and the tree-model snapshots [depth][2][28] behind them */
-    CARVE(snap, max_save ? (size_t) (FC_MAXDEPTH_BIG * 5 * 82 + FC_MAXDEPTH_BIG * 2 * 28) * 16
-                         : (size_t) 26 * 2 * 82 * 16);
+    const size_t n16max = FC_N16(hm ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD);        /* the kernel build's FC_N16MAX */
+    CARVE(snap, max_save ? (size_t) (FC_MAXDEPTH_BIG * 5 * n16max + FC_MAXDEPTH_BIG * 2 * 28) * 16
+                         : (size_t) 26 * 2 * n16max * 16);
     /* prediction: second table set for residual blocks, block pixels + norms, displaced rows */
     CARVE(ipis_alt, max_save ? (size_t) NS * P * 4 : 0);
     CARVE(d5_alt, max_save ? (size_t) NA * P * 4 : 0);
@@ -633,10 +644,6 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         snprintf(why, n, "prediction over more than 9 block levels is not supported by the device coder");
         return 0;
     }
-    if (job->image->color && cp->chroma_max_states > 63) {
-        snprintf(why, n, "device coder supports chroma dictionaries of at most 63 states");
-        return 0;
-    }
     if (cp->images_level != 5 || cp->lc_min_level < 4) {
         snprintf(why, n, "device coder needs images_level 5 and min block level >= 4");
         return 0;
@@ -645,14 +652,14 @@ static int device_supported(const fa_job *job, char *why, size_t n)
     if (cp->max_elements > 5) { snprintf(why, n, "more than 5 vectors per block are not supported by the device coder"); return 0; }
     {
         unsigned dcs = 1u << (1 + cp->dc_rpf.mantissa_bits), sy = 1u << (1 + cp->rpf.mantissa_bits);
-        if ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF_BIG) {
+        if ((cp->lc_max_level - cp->lc_min_level + 1) * sy + dcs > FC_MAXCOEFF_HM) {
             snprintf(why, n, "coefficient model too large for the device coder "
-                             "(block levels x mantissa symbols > %d)", FC_MAXCOEFF_BIG);
+                             "(block levels x mantissa symbols > %d)", FC_MAXCOEFF_HM);
             return 0;
         }
     }
-    if (cp->rpf.mantissa_bits > 5 || cp->dc_rpf.mantissa_bits > 5) {
-        snprintf(why, n, "RPF mantissa > 5 bits is not supported by the device coder yet");
+    if (cp->rpf.mantissa_bits > 8 || cp->dc_rpf.mantissa_bits > 8 || cp->d_rpf.mantissa_bits > 8 || cp->d_dc_rpf.mantissa_bits > 8) {
+        snprintf(why, n, "RPF mantissa > 8 bits is not supported by the device coder");      /* (alloc_rpf never makes one) */
         return 0;
     }
     if (long_basis(job->wfa)) {
@@ -694,6 +701,7 @@ struct FrameSlot {
     Layout   L;
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
+    bool     hm = false;         /* coefficient models of more than 64 symbols per context: the FC_HM kernel build */
     bool     wide_only = false;  /* default geometry, but beyond the 256-thread build's LDS pools */
     bool     tri = false;        /* triangular Gram tables (half the slab; the wide_tri build of the kernel) */
     bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
@@ -991,7 +999,7 @@ static void slot_layout(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm);
 }
 
 /* ---- frame queue: which frames may share slabs ---- */
@@ -1000,7 +1008,7 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
     /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
-    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !long_basis(job->wfa) && !fa_knob("FIASCO_AMD_NO_QUEUE");
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !long_basis(job->wfa) && !fs.hm && !fa_knob("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
@@ -1068,7 +1076,7 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     /* developer aid: FIASCO_AMD_POISON=<byte> fills the slab first -- the kernel must write every
      * cell before it reads it, whatever an earlier frame left there */
@@ -1079,9 +1087,12 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         return 0;
     }
     fill_frame(fs, job);
-    if (fs.F.coeff_size > (fs.big ? FC_MAXCOEFF_BIG : FC_MAXCOEFF) || fs.F.dcs > FC_MAXSYM || fs.F.sy > FC_MAXSYM || fs.F.ML > 26) {
+    const int maxsym = fs.hm ? FC_MAXSYM_HM : FC_MAXSYM_STD;
+    if (fs.F.coeff_size > (fs.hm ? FC_MAXCOEFF_HM : fs.big ? FC_MAXCOEFF_BIG_STD : FC_MAXCOEFF) || fs.F.dcs > maxsym || fs.F.sy > maxsym
+        || (fs.F.pred_on && (fs.F.d_coeff_size > (fs.hm ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD) || fs.F.d_dcs > maxsym || fs.F.d_sy > maxsym))
+        || fs.F.ML > 26) {
         snprintf(job->errmsg, sizeof job->errmsg,
-                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", FC_MAXCOEFF_BIG);
+                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", fs.hm ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD);
         slab_release(fs.base, fs.bytes); fs.base = nullptr;
         fs.done = true; fs.rejected = true;      /* permanent: not a matter of free HBM */
         return 0;
@@ -1251,7 +1262,10 @@ static void *core1_stage(unsigned n, fa_job *jobs)
         FrameSlot fs;
         fs.job = (int) i;
         fs.P = (int) align_up(guess, 64);
-        fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME;
+        fs.big = needs_big_variant(cp, jobs[i].wfa) || jobs[i].frame_type != FA_I_FRAME
+                 /* a chroma dictionary of more than 63 states: the list scan of the big builds (mp_steps_list_global) */
+                 || (jobs[i].image->color && cp->chroma_max_states > 63);
+        fs.hm = needs_hm_variant(cp);
         fs.wide_only = !fs.big && needs_wide_variant(cp);
                 /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
         const bool build1 = !specG && fa_knob("FIASCO_AMD_SPEC_BUILD1") != nullptr;
@@ -1295,7 +1309,7 @@ static void *core1_stage(unsigned n, fa_job *jobs)
         size_t free_b = 0, total_b = 0, pooled = 0;
         for (size_t i = 0; i < g_free.size(); i++) pooled += g_free[i].bytes;
         size_t want = S->slots.size();
-        const size_t resident = (size_t) cus * frames_per_cu(probe.big, probe.P > 12 * 256 || probe.wide_only);
+        const size_t resident = (size_t) cus * frames_per_cu(probe.big, probe.P > 12 * 256 || probe.wide_only || probe.hm);
         if (want > resident) want = resident;
         const bool hbm_bound = hipMemGetInfo(&free_b, &total_b) == hipSuccess && probe.L.total * want > free_b + pooled;
         if ((hbm_bound || S->slots.size() > resident) && queue_eligible(S, probe)) {
@@ -1351,7 +1365,7 @@ static void *core1_stage(unsigned n, fa_job *jobs)
                 S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big; S->qtri = fs.tri;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (wide build for P > 3072: one per CU) */
-                S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only);
+                S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only || fs.hm);
                 if (fa_knob("FIASCO_AMD_QUEUE_SLABS") && atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS")) > 0)
                     S->lender_cap = (size_t) atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
             } else if (elig && queue_layout(S, fs)) S->lenders++;
@@ -1606,7 +1620,7 @@ static bool launch_wave(Staged *S)
      * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[7] = { 0, 0, 0, 0, 0, 0, 0 }, group_lend[7] = { 0, 0, 0, 0, 0, 0, 0 }, group_borrow[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    size_t group_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, group_lend[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, group_borrow[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1616,23 +1630,23 @@ static bool launch_wave(Staged *S)
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
-        for (int g = 0; g < 7; g++)
+        for (int g = 0; g < 8; g++)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
-                    /* groups 5, 6: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
+                    /* group 5: the FC_HM build; groups 6, 7: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
                     const bool spec = fs.spec && (S->specG >= 2 || fa_knob("FIASCO_AMD_SPEC_BUILD1")) && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
                     /* (FIASCO_AMD_SPEC_WIDE=0 / 1: experiments with the width of the workgroups) */
                     const char *sw = fa_knob("FIASCO_AMD_SPEC_WIDE");
                     const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only || (sw && atoi(sw) == 1));
-                    if ((spec ? (spec_wide ? 6 : 5) : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
+                    if ((spec ? (spec_wide ? 7 : 6) : fs.hm ? 5 : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
                     ordered.push_back(batch[b]);
                     group_n[g]++;
-                    if (g < 5) g_stats.frames_by_build[g]++; else g_stats.spec_frames++;
+                    if (g < 5) g_stats.frames_by_build[g]++; else if (g == 5) g_stats.frames_by_build[3]++; else g_stats.spec_frames++;
                     if (part == 0) group_lend[g]++; else if (part == 1) group_borrow[g]++;
                 }
         batch.swap(ordered);
@@ -1677,21 +1691,21 @@ static bool launch_wave(Staged *S)
     bool fail = false;
     S->spec_frames.clear();
     S->spec_first[0] = S->spec_first[1] = 0; S->spec_n[0] = S->spec_n[1] = 0;
-    if (group_n[5] + group_n[6] && S->specG < 2) {       /* FIASCO_AMD_SPEC_BUILD1: the build alone */
-        const size_t nall = group_n[5] + group_n[6], first_all = batch.size() - nall;
-        S->spec_first[0] = first_all; S->spec_n[0] = group_n[5];
-        S->spec_first[1] = first_all + group_n[5]; S->spec_n[1] = group_n[6];
+    if (group_n[6] + group_n[7] && S->specG < 2) {       /* FIASCO_AMD_SPEC_BUILD1: the build alone */
+        const size_t nall = group_n[6] + group_n[7], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[6];
+        S->spec_first[1] = first_all + group_n[6]; S->spec_n[1] = group_n[7];
         for (size_t i = 0; i < nall; i++) hf[first_all + i].spec = nullptr;
-    } else if (group_n[5] + group_n[6]) {
+    } else if (group_n[6] + group_n[7]) {
         /* the speculating frames (groups 5 and 6: 256 / 1024 threads per workgroup; they are the last of
          * the batch): control block + checkpoint slots + block list + table ring per frame, then per
          * verifier workgroup its private <sub-block, state> tables, scan scratch and pool list; verifier
          * v of a frame owns the state ids [P - 16 v, P - 16 (v - 1)) */
         const int G = S->specG;
         const int T = spec_workers(G), NV = G - 1 - T;           /* table workers, verifiers */
-        const size_t nall = group_n[5] + group_n[6], first_all = batch.size() - nall;
-        S->spec_first[0] = first_all; S->spec_n[0] = group_n[5];
-        S->spec_first[1] = first_all + group_n[5]; S->spec_n[1] = group_n[6];
+        const size_t nall = group_n[6] + group_n[7], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[6];
+        S->spec_first[1] = first_all + group_n[6]; S->spec_n[1] = group_n[7];
         /* one span for every frame of the launch (sized for the largest) */
         size_t max_blocks = 0, max_tab = 0, max_slot = 0;
         std::vector<std::vector<uint16_t>> lists(nall);
@@ -1701,7 +1715,7 @@ static bool launch_wave(Staged *S)
             if (lists[i].size() / 2 > max_blocks) max_blocks = lists[i].size() / 2;
             const size_t tab = align_up(((size_t) F.NS + (size_t) F.NA) * (size_t) F.P * 4, 256);
             if (tab > max_tab) max_tab = tab;
-            const size_t slot = i < group_n[5] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
+            const size_t slot = i < group_n[6] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
             if (slot > max_slot) max_slot = slot;
         }
         const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) 2 * FC_SPEC_W * max_slot, 256);      /* checkpoint + result slots */
@@ -1798,7 +1812,7 @@ static bool launch_wave(Staged *S)
         /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
         unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
         if (fa_knob("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_QUEUE_WAIT_MS"));
-        static const launch_fn launch[5] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri };
+        static const launch_fn launch[6] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri, fc_launch_big_hm };
         size_t first = 0;
         for (int k = 0; k < 2 && !fail; k++) {
             if (!S->spec_n[k]) continue;
@@ -1809,7 +1823,7 @@ static bool launch_wave(Staged *S)
             (k ? fc_launch_spec_wide : fc_launch_spec)(S->d_frames + S->spec_first[k], vfr, (unsigned) S->spec_n[k],
                                                        on ? (unsigned) S->specG : 1u, S->stream);
         }
-        for (int g = 0; g < 5 && !fail; g++) {
+        for (int g = 0; g < 6 && !fail; g++) {
             size_t plain = group_n[g], at = first;
             if (group_borrow[g]) {
                 /* the queue: group_lend[g] frames with slabs first, then the frames that borrow one */

@@ -41,8 +41,21 @@
 #define FC_SNAPTM_WIDE   1092   /* 21 depths x 13 uint4 */
 #define FC_MAXSAVE  512         /* states a prediction attempt can displace: 2^(12 - 4 + 1) */
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */
-#define FC_MAXCOEFF_BIG 640     /* big build: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
-#define FC_MAXSYM   64          /* symbols per context (mantissa <= 5) */
+/* FC_HM: the "high mantissa" build of the kernel (RPF mantissas of 6 .. 8 bits, codec/options.c:510-553: up to
+ * 512 symbols per context, 9 x 512 + 512 counters) -- the 512-thread big build with the coefficient models
+ * and their log2 tables sized for that (one frame per CU has the LDS for it) */
+#ifndef FC_HM
+#define FC_HM 0
+#endif
+#define FC_MAXCOEFF_BIG_STD 640     /* big builds: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
+#define FC_MAXSYM_STD   64          /* symbols per context (mantissa <= 5) */
+#define FC_MAXCOEFF_HM  5120        /* FC_HM: 9 levels x 512 symbols + 512 (mantissas up to 8 bits) */
+#define FC_MAXSYM_HM    512
+#define FC_MAXCOEFF_BIG (FC_HM ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD)
+#define FC_MAXSYM       (FC_HM ? FC_MAXSYM_HM : FC_MAXSYM_STD)
+/* uint4 (16-byte units) of an aac snapshot of the largest model: totals + counters */
+#define FC_N16(coeffs)  ((32 + 2 * (coeffs) + 15) / 16)
+#define FC_N16MAX       FC_N16(FC_MAXCOEFF_BIG)       /* 82, FC_HM: 643 */
 #define FC_MAXBASIS 16          /* states of an initial basis that travels inside DevFrame (else DevFrame.bx) */
 #define FC_BX_BYTES (64 * 1024)  /* room for DevFrame.bx in a slab: 2700 basis states */
 #define FC_TRI_HOT  8           /* states whose Gram columns the triangular layout also keeps as rows (DevFrame.gcol) */

@@ -69,8 +69,15 @@
 #ifndef FC_VARIANT_BIG
 #define FC_VARIANT_BIG 0
 #endif
+#if FC_HM && !(FC_VARIANT_BIG && FC_VARIANT_WIDE)
+#error "FC_HM is a variant of the 512-thread big build"
+#endif
 #if FC_VARIANT_BIG
-#if FC_VARIANT_WIDE
+#if FC_HM
+#define FC_KERNEL    fiasco_frame_kernel_big_hm
+#define FC_LAUNCH    fc_launch_big_hm
+#define FC_OCCUPANCY fc_occupancy_big_hm
+#elif FC_VARIANT_WIDE
 #define FC_KERNEL    fiasco_frame_kernel_big_wide
 #define FC_LAUNCH    fc_launch_big_wide
 #define FC_OCCUPANCY fc_occupancy_big_wide
@@ -1491,6 +1498,73 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     if (F.frame_type) { subtract_mc_dev(F, sh); __syncthreads(); }     /* codec/coder.c:798-799 */
 #endif
     if (tid == 0) { sh.lc_min = F.ML; sh.ystates = states; }
+    /* chroma dictionaries of more than 63 states (cfiasco --chroma-dictionary 64 ..; big builds): the list does not
+     * fit sh.dl / one wave -- it lives in F.pool_states, the search is mp_steps_list_global */
+    const bool longl = FC_VARIANT_BIG && maxd > 63;
+    if (longl && maxd < (int) m.n) {
+        uint8_t *const mark = F.used;                     /* [P] scratch of the general scan: free between the bands */
+        for (int d = tid; d < to; d += B) { __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mark[d] = 0; }
+        __syncthreads();
+        for (int s = F.basis_states + tid; s <= to; s += B)
+            for (int l = 0; l < 2; l++)
+                for (int e = 0, d; (d = INTO(F, s, l, e)) != NOEDGE; e++)
+                    __hip_atomic_fetch_add(&F.hits[d], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        unsigned long long best = 0;
+        for (int d = 1 + tid; d < to; d += B) {
+            int k = (short) __hip_atomic_load(&F.hits[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long pk = ((unsigned long long) (unsigned) k << 32) | (0xffffffffu - (unsigned) d);
+            if (k > 0 && pk > best) best = pk;
+        }
+        int n = maxd < to ? maxd : to, npick = 0;
+        if (n > 0) { if (tid == 0) mark[0] = 1; npick = 1; }
+        unsigned long long *red = sh.red;
+        while (npick < n) {                              /* the same rounds as below; a pick is a mark */
+            unsigned long long w = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long t = __shfl_xor(w, o);
+                if (t > w) w = t;
+            }
+            if (lane == 0) red[wave] = w;
+            __syncthreads();
+            unsigned long long g = red[0];
+#pragma unroll
+            for (int i = 1; i < B / 64; i++) if (red[i] > g) g = red[i];
+            if (g == 0) break;
+            int d = (int) (0xffffffffu - (unsigned) (g & 0xffffffffu));
+            npick++;
+            if (best == g) {
+                mark[d] = 1;
+                __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best = 0;
+                for (int dd = 1 + tid; dd < to; dd += B) {
+                    int k = (short) __hip_atomic_load(&F.hits[dd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long pk = ((unsigned long long) (unsigned) k << 32) | (0xffffffffu - (unsigned) dd);
+                    if (k > 0 && pk > best) best = pk;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        /* the kept states in ascending order (wfalib.c:226): every lane compacts its share of the marks */
+        int *const scr = (int *) sh.pixels;              /* B counters; the block's pixels are not needed between the bands */
+        const int chunk = (to + B - 1) / B, lo = tid * chunk, hi = lo + chunk < to ? lo + chunk : to;
+        int cnt = 0;
+        for (int d = lo; d < hi; d++) cnt += mark[d];
+        scr[tid] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int t = 0; t < B; t++) { const int c = scr[t]; scr[t] = acc; acc += c; }
+            m.n = (unsigned short) acc;
+        }
+        __syncthreads();
+        int o = scr[tid];
+        for (int d = lo; d < hi; d++) if (mark[d]) F.pool_states[o++] = (short) d;
+    } else if (longl) {
+        /* every pool state stays in the list (F.pool_states as it is) */
+    } else
     if (maxd < (int) m.n) {
         /* histogram in HBM with device-scope atomics; read back past the L1 */
         for (int d = tid; d < to; d += B) __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1564,7 +1638,8 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     }
     atomicMin(&sh.lc_min, mn);
     __syncthreads();
-    if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
+    if (longl) { for (int i = tid; i < (int) m.n; i += B) F.pos[F.pool_states[i]] = (short) i; }
+    else if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
 }
 
 #if FC_VARIANT_BIG
@@ -1605,10 +1680,18 @@ __device__ void block_norms(Sh &sh, int level, int ns)
 __device__ void swap_model_sets(Sh &sh)
 {
     const int tid = threadIdx.x;
+#if FC_HM           /* models of more 16-byte units than lanes */
+    for (int i = tid; i < sh.n16; i += B) {
+        uint4 a = ((uint4 *) &sh.cb)[i], b = ((uint4 *) &sh.dcb)[i];
+        ((uint4 *) &sh.cb)[i] = b; ((uint4 *) &sh.dcb)[i] = a;
+    }
+    if (tid == 128) {
+#else
     if (tid < sh.n16) {
         uint4 a = ((uint4 *) &sh.cb)[tid], b = ((uint4 *) &sh.dcb)[tid];
         ((uint4 *) &sh.cb)[tid] = b; ((uint4 *) &sh.dcb)[tid] = a;
     } else if (tid == 128) {
+#endif
         Pool t = sh.pool; sh.pool = sh.dpool; sh.dpool = t;
     } else if (tid == 129) {
         int i; float f;
@@ -2042,6 +2125,16 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
 __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, int ML)
 {
     const int tid = threadIdx.x;
+#if FC_HM
+    for (int i = tid; i < sh.n16; i += B) SNAP_AT(sh, depth, 0)[i] = ((const uint4 *) &sh.cb)[i];
+    if (tid >= 96 && tid < 96 + TM_N16(ML)) TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
+    if (tid == 128) fr.pool0 = sh.pool;
+    if (sh.nslot == 5 && !fr.delta) {
+        if (tid == 129) fr.dpool0 = sh.dpool;
+        for (int i = tid; i < sh.n16; i += B) SNAP_AT(sh, depth, 2)[i] = ((const uint4 *) &sh.dcb)[i];
+    }
+    return;
+#endif
     if (tid < sh.n16) SNAP_AT(sh, depth, 0)[tid] = ((const uint4 *) &sh.cb)[tid];
     else if (tid >= 96 && tid < 96 + TM_N16(ML))   /* n16 <= 82 (FC_MAXCOEFF_BIG), ML <= 26 */
         TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
@@ -2059,10 +2152,18 @@ __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, 
 __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
 {
     const int tid = threadIdx.x;
+#if FC_HM
+    for (int i = tid; i < sh.n16; i += B) {
+        SNAP_AT(sh, depth, 1)[i] = ((const uint4 *) &sh.cb)[i];
+        ((uint4 *) &sh.cb)[i] = SNAP_AT(sh, depth, 0)[i];
+    }
+    if (tid == 128) {
+#else
     if (tid < sh.n16) {
         SNAP_AT(sh, depth, 1)[tid] = ((const uint4 *) &sh.cb)[tid];
         ((uint4 *) &sh.cb)[tid] = SNAP_AT(sh, depth, 0)[tid];
     } else if (tid == 128) {
+#endif
         fr.pool_lc = sh.pool;
         sh.pool = fr.pool0;
     }
@@ -3493,7 +3594,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
          * the area, tree-model snapshots behind them */
         sh.snap = (F.pred_on || (F.level - F.lc_min + 3) * 2 * sh.n16 > SNAP_POOL16) && F.snap_hbm
                   ? (uint4 *) F.snap_hbm : sh.snap_pool;
-        sh.snap_tm_p = F.pred_on && F.snap_hbm ? (uint4 *) F.snap_hbm + FC_DEPTH * 5 * 82 : (uint4 *) sh.snap_tm;
+        sh.snap_tm_p = F.pred_on && F.snap_hbm ? (uint4 *) F.snap_hbm + FC_DEPTH * 5 * FC_N16MAX : (uint4 *) sh.snap_tm;
         sh.pred_active = 0; sh.pred_lo = sh.pred_rec = 0;
 #endif
         {

@@ -2,7 +2,8 @@
 reference coder (oracle/_ref/cfiasco_ref, built from /root/reference by oracle/ref_build.sh).
 
 Random gray/colour images x random option sets the reference CLI can express (quality, -z 0..2,
-dictionary size, RPF mantissas and ranges, chroma options, tiling options, 1..3-frame all-intra
+dictionary size, RPF mantissas 2..8 and ranges, chroma options incl. dictionaries of 64..200 states, initial
+bases, tiling options, 1..3-frame all-intra
 streams; with FUZZ_VIDEO=1 also intra prediction, prediction levels and 2..5-frame streams with
 P and B frames whose frames are displaced, noisy copies of the first) are encoded by both
 command-line coders; the streams must be identical, or both must
@@ -56,8 +57,13 @@ def one(seed):
             "--dictionary-size", str(rng.choice([1, 8, 40, 300, 10000])),
             "--rpf-mantissa", str(int(rng.integers(2, 9))), "--dc-rpf-mantissa", str(int(rng.integers(2, 9))),
             "--rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])), "--dc-rpf-range", str(rng.choice([0.75, 1.0, 1.5, 2.0])),
-            "--chroma-qfactor", str(rng.choice([1.0, 2.0, 3.5])), "--chroma-dictionary", str(rng.choice([1, 5, 40, 63, 100])),
+            "--chroma-qfactor", str(rng.choice([1.0, 2.0, 3.5])), "--chroma-dictionary", str(rng.choice([1, 5, 40, 63, 64, 100, 200])),
             "--tiling-exponent", str(int(rng.integers(0, 6))), "--pattern", pattern] + extra
+    # round 5: initial bases whose edge lists run past MAXEDGES -- our own (tests/golden/long_*.fco) and the
+    # reference's medium.fco / large.fco (oracle/_ref/share, installed by oracle/ref_build.sh)
+    basis = str(rng.choice(["", "", "", "long_a.fco", "long_b.fco", "long_c.fco", "medium.fco", "large.fco"]))
+    if basis:
+        args += ["--basis-name", basis]
     ref, ora_extra = REF, []
     if HUGE:
         ref, ora_extra = REF_BIG, ["--limit-states", "30000", "--limit-level", "26"]
@@ -83,7 +89,7 @@ def one(seed):
                 a = rng.integers(0, 256, (h, w, 3) if colour else (h, w)).astype(np.uint8)
                 (synth.write_ppm if colour else synth.write_pgm)(p, a)
             names.append(p)
-        env = dict(os.environ, FIASCO_DATA="/root/reference/data")
+        env = dict(os.environ, FIASCO_DATA=os.path.join(HERE, "golden") + ":" + os.path.join(ROOT, "oracle", "_ref", "share"))
         r = subprocess.run([ref, "--progress-meter", "0"] + args + ["-o", os.path.join(td, "r.fco")] + names,
                            env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         if r.returncode < 0 or r.returncode >= 128:

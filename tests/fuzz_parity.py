@@ -23,6 +23,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fiasco_amd
 import synth
 
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FIASCO_DATA", os.path.join(_ROOT, "tests", "golden") + ":" + os.path.join(_ROOT, "oracle", "_ref", "share"))
+
 
 def random_image(rng, colour):
     big = int(os.environ.get("FUZZ_BIG", "0"))          # FUZZ_BIG=1: sizes up to 1000 x 800
@@ -58,9 +61,9 @@ def random_options(rng, lib=None):
     el = int(rng.integers(1, 6))
     lvl = int(rng.integers(0, 3))                       # 2: retries + full_search (cfiasco -z 3)
     dic = int(rng.choice([8, 40, 300, 10000]))
-    mant = int(rng.integers(2, 6)); dmant = int(rng.integers(2, 6))
+    mant = int(rng.integers(2, 9)); dmant = int(rng.integers(2, 9))        # 6 .. 8: the FC_HM kernel build
     rr = int(rng.integers(0, 4)); dr = int(rng.integers(0, 4))
-    cq = float(rng.choice([1.0, 2.0, 3.5])); cd = int(rng.choice([1, 5, 40, 63]))
+    cq = float(rng.choice([1.0, 2.0, 3.5])); cd = int(rng.choice([1, 5, 40, 63, 64, 100, 200]))
     pred = (0, 6, 10)
     if os.environ.get("FUZZ_PRED") == "1" and rng.integers(0, 4):     # intra prediction (ND)
         plo = int(rng.integers(6, 11))
@@ -68,12 +71,20 @@ def random_options(rng, lib=None):
     if os.environ.get("FUZZ_SPEC") == "1":
         lo, hi, el, lvl, pred = 6, 10, int(rng.integers(1, 4)), 0, (0, 6, 10)
         mant = int(rng.integers(2, 5))
-    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred)
+    # initial basis: the built-in one, our own long ones (tests/golden/make_basis.py), the reference's where installed
+    share = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "share", "medium.fco")
+    names = ["", "", "", "long_a.fco", "long_b.fco", "long_c.fco"] + (["medium.fco", "large.fco"] if os.path.exists(share) else [])
+    basis = str(rng.choice(names))
+    if os.environ.get("FUZZ_SPEC") == "1":
+        basis = ""
+    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis)
     return spec
 
 
 def apply(o, spec):
-    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred = spec
+    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis = spec
+    if basis:
+        o.set_basisfile(basis.encode())
     o.set_prediction(*pred)
     o.set_optimizations(lo, hi, el, dic, lvl)
     o.set_quantization(mant, rr, dmant, dr)

@@ -752,6 +752,7 @@ struct Staged {
      * other), a stream of their own and the event the next launch waits for */
     char  *up_host = nullptr;
     size_t up_host_bytes = 0;
+    bool   up_host_shared = false;   /* the buffer belongs to the batch of several shares (MultiStaged): not freed here */
     char  *up_dev[2] = { nullptr, nullptr };
     size_t up_dev_bytes[2] = { 0, 0 };
     int    up_parity = 0;
@@ -1186,7 +1187,7 @@ static void core1_unstage(void *h)
     if (S->pinned) (void) hipHostFree(S->pinned);
     if (S->ustream) { (void) hipStreamSynchronize(S->ustream); (void) hipStreamDestroy(S->ustream); }
     if (S->ev_up) (void) hipEventDestroy(S->ev_up);
-    if (S->up_host) (void) hipHostFree(S->up_host);
+    if (S->up_host && !S->up_host_shared) (void) hipHostFree(S->up_host);
     for (int i = 0; i < 2; i++) if (S->up_dev[i]) (void) hipFree(S->up_dev[i]);
     if (S->ev0) (void) hipEventDestroy(S->ev0);
     if (S->ev1) (void) hipEventDestroy(S->ev1);
@@ -1393,8 +1394,9 @@ static int16_t *core1_upload_buffer(void *h, size_t bytes)
     if (!S || !S->ok || !bytes) return nullptr;
     /* the previous upload has left this memory long ago (a whole pass lies in between) */
     if (S->ustream) (void) hipStreamSynchronize(S->ustream);
-    if (bytes > S->up_host_bytes) {
-        if (S->up_host) (void) hipHostFree(S->up_host);
+    if (bytes > S->up_host_bytes || S->up_host_shared) {
+        if (S->up_host && !S->up_host_shared) (void) hipHostFree(S->up_host);
+        S->up_host_shared = false;
         S->up_host = nullptr; S->up_host_bytes = 0;
         if (hipHostMalloc((void **) &S->up_host, bytes, hipHostMallocDefault) != hipSuccess) {
             S->up_host = nullptr; (void) hipGetLastError();
@@ -1415,9 +1417,10 @@ static int core1_upload_commit(void *h)
     if (!S->ev_up && hipEventCreateWithFlags(&S->ev_up, hipEventDisableTiming) != hipSuccess) {
         S->ev_up = nullptr; (void) hipGetLastError(); return 0;
     }
-    /* the buffer the RUNNING pass does not read */
+    /* the buffer the RUNNING pass does not read; it holds the planes of THIS share's frames back to back (with
+     * several shares the frames of a share are every D-th of the caller's buffer): one copy per frame */
     const int p = S->up_parity ^ 1;
-    size_t lo = (size_t) -1, hi = 0;
+    size_t need = 0;
     for (size_t k = 0; k < S->slots.size(); k++) {
         const fa_image *im = S->jobs[S->slots[k].job].image;
         const size_t npix = (size_t) im->width * im->height * (im->color ? 3 : 1);
@@ -1426,31 +1429,35 @@ static int core1_upload_commit(void *h)
             fa_set_error("upload: frame planes lie outside the upload buffer");
             return 0;
         }
-        if (o < lo) lo = o;
-        if (o + npix * 2 > hi) hi = o + npix * 2;
+        need += align_up(npix * 2, 256);
     }
-    if (hi <= lo) return 1;                      /* nothing the device can encode */
-    if (S->up_host_bytes > S->up_dev_bytes[p]) {
+    if (!need) return 1;                         /* nothing the device can encode */
+    if (need > S->up_dev_bytes[p]) {
         if (S->up_dev[p]) (void) hipFree(S->up_dev[p]);
         S->up_dev[p] = nullptr; S->up_dev_bytes[p] = 0;
-        if (hipMalloc((void **) &S->up_dev[p], S->up_host_bytes) != hipSuccess) {
+        if (hipMalloc((void **) &S->up_dev[p], need) != hipSuccess) {
             S->up_dev[p] = nullptr; (void) hipGetLastError();
-            fa_set_error("out of HBM: no room for %.1f MiB of replacement frames", S->up_host_bytes / 1048576.0);
+            fa_set_error("out of HBM: no room for %.1f MiB of replacement frames", need / 1048576.0);
             return 0;
         }
-        S->up_dev_bytes[p] = S->up_host_bytes;
+        S->up_dev_bytes[p] = need;
     }
-    if (hipMemcpyAsync(S->up_dev[p] + lo, S->up_host + lo, hi - lo, hipMemcpyHostToDevice, S->ustream) != hipSuccess
-        || hipEventRecord(S->ev_up, S->ustream) != hipSuccess) {
-        fa_set_error("HIP error: %s", hipGetErrorString(hipGetLastError()));
-        return 0;
-    }
-    for (size_t k = 0; k < S->slots.size(); k++) {
-        FrameSlot &fs = S->slots[k];
-        const fa_image *im = S->jobs[fs.job].image;
-        /* taken over by the next submit: a re-encode of the RUNNING pass (capacity guess too
-         * small) still reads that pass's frames */
-        fs.ext_next = (const int16_t *) (S->up_dev[p] + ((const char *) im->pixels[0] - S->up_host));
+    {
+        size_t at = 0;
+        bool fail = false;
+        for (size_t k = 0; k < S->slots.size() && !fail; k++) {
+            const fa_image *im = S->jobs[S->slots[k].job].image;
+            const size_t len = (size_t) im->width * im->height * (im->color ? 3 : 1) * 2;
+            fail = hipMemcpyAsync(S->up_dev[p] + at, im->pixels[0], len, hipMemcpyHostToDevice, S->ustream) != hipSuccess;
+            /* taken over by the next submit: a re-encode of the RUNNING pass (capacity guess too
+             * small) still reads that pass's frames */
+            S->slots[k].ext_next = (const int16_t *) (S->up_dev[p] + at);
+            at += align_up(len, 256);
+        }
+        if (fail || hipEventRecord(S->ev_up, S->ustream) != hipSuccess) {
+            fa_set_error("HIP error: %s", hipGetErrorString(hipGetLastError()));
+            return 0;
+        }
     }
     S->up_pending = true;
     return 1;
@@ -2251,7 +2258,9 @@ extern "C" void fiasco_amd_get_stats(fiasco_amd_stats *out)
         const unsigned long long *v = (const unsigned long long *) ((const char *) &b + sizeof(double));
         const size_t nw = (sizeof(fiasco_amd_stats) - sizeof(double)) / sizeof(unsigned long long);
         const size_t imax = (offsetof(fiasco_amd_stats, states_max) - sizeof(double)) / sizeof(unsigned long long);
-        for (size_t i = 0; i < nw; i++) o[i] = i == imax ? (o[i] > v[i] ? o[i] : v[i]) : o[i] + v[i];
+        /* workgroups per frame of the table passes: a setting, the same on every share -- not a sum */
+        const size_t icoop = (offsetof(fiasco_amd_stats, coop_workgroups) - sizeof(double)) / sizeof(unsigned long long);
+        for (size_t i = 0; i < nw; i++) o[i] = i == imax || i == icoop ? (o[i] > v[i] ? o[i] : v[i]) : o[i] + v[i];
         if (b.kernel_ms > out->kernel_ms) out->kernel_ms = b.kernel_ms;
     }
 }
@@ -2266,39 +2275,102 @@ struct MultiStaged {
     fa_job  *jobs = nullptr;
     struct Part { std::vector<unsigned> idx; std::vector<fa_job> sub; void *staged = nullptr; int good = 0; };
     std::vector<Part> parts;        /* one share: parts[0].staged works on jobs[] itself, nothing is copied */
+    char  *up_host = nullptr;       /* several shares: the pinned buffer of fa_core_upload_buffer (the shares borrow it) */
+    size_t up_host_bytes = 0;
 };
 
-/* run fn(share) for every share: share 0 on the calling thread, the others on threads of their own,
- * each bound to its device and its DevState for the duration of the call */
+/* One persistent host thread per share k >= 1 (created at its first use, parked on a condition variable between
+ * calls): a phase of a batch -- stage, submit, finish, upload -- posts its share of the work there instead of
+ * creating and joining a thread each time.  A worker binds itself to the device of its share, g_devices[k], at
+ * the start of every task (the list may have changed since) and works on the share's DevState. */
+struct ShareWorker {
+    pthread_t th;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    void (*call)(void *, size_t) = nullptr;
+    void *ctx = nullptr;
+    size_t k = 0;
+    int state = 0;                  /* 0 idle, 1 task posted, 2 task done */
+};
+static std::vector<ShareWorker *> g_workers;       /* [k], k >= 1; [0] unused */
+
+static void bind_share(size_t k)
+{
+    t_dev = k < g_dev_state.size() ? g_dev_state[k] : &g_state0;
+    if (k < g_devices.size() && g_devices[k] >= 0) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != g_devices[k]) { (void) hipGetLastError(); (void) hipSetDevice(g_devices[k]); }
+    }
+}
+
+static void *share_worker_main(void *p)
+{
+    ShareWorker *w = (ShareWorker *) p;
+    for (;;) {
+        pthread_mutex_lock(&w->mu);
+        while (w->state != 1) pthread_cond_wait(&w->cv, &w->mu);
+        pthread_mutex_unlock(&w->mu);
+        bind_share(w->k);
+        w->call(w->ctx, w->k);
+        pthread_mutex_lock(&w->mu);
+        w->state = 2;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+    }
+    return nullptr;
+}
+
+static ShareWorker *share_worker(size_t k)
+{
+    pthread_mutex_lock(&g_dev_lock);
+    while (g_workers.size() <= k) g_workers.push_back(nullptr);
+    ShareWorker *w = g_workers[k];
+    if (!w) {
+        w = new ShareWorker;
+        w->k = k;
+        if (pthread_create(&w->th, nullptr, share_worker_main, w) != 0) { delete w; w = nullptr; }
+        else { (void) pthread_detach(w->th); g_workers[k] = w; }
+    }
+    pthread_mutex_unlock(&g_dev_lock);
+    return w;
+}
+
+/* run fn(share) for every share: share 0 on the calling thread, the others on their workers; EVERY share --
+ * also the only one of a call -- runs bound to its device g_devices[k] with the DevState of that share (the slab
+ * pool of a share never sees another device), and the caller's current device is what it was afterwards */
 template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
 {
     const size_t D = M->parts.size();
-    if (D == 1) { fn(0); return; }
-    struct Arg { Fn *fn; size_t k; };
-    std::vector<pthread_t> th(D);
-    std::vector<Arg> arg(D);
-    std::vector<char> started(D, 0);
-    auto body = [](void *p) -> void * {
-        Arg *a = (Arg *) p;
-        t_dev = g_dev_state[a->k];
-        if (g_devices[a->k] >= 0) (void) hipSetDevice(g_devices[a->k]);
-        (*a->fn)(a->k);
-        return nullptr;
-    };
     int cur = -1;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (!have_cur) (void) hipGetLastError();
+    auto tramp = [](void *p, size_t k) { (*(Fn *) p)(k); };
+    std::vector<ShareWorker *> posted(D, nullptr);
     for (size_t k = 1; k < D; k++) {
-        arg[k].fn = &fn; arg[k].k = k;
-        started[k] = pthread_create(&th[k], nullptr, body, &arg[k]) == 0;
+        ShareWorker *w = share_worker(k);
+        if (!w) continue;
+        pthread_mutex_lock(&w->mu);
+        w->call = tramp; w->ctx = &fn; w->state = 1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        posted[k] = w;
     }
-    arg[0].fn = &fn; arg[0].k = 0;
-    body(&arg[0]);                                  /* share 0 here (t_dev == &g_state0 already) */
+    bind_share(0);
+    fn(0);
     for (size_t k = 1; k < D; k++) {
-        if (started[k]) pthread_join(th[k], nullptr);
-        else { body(&arg[k]); t_dev = &g_state0; }   /* no thread: one after the other */
+        if (posted[k]) {
+            ShareWorker *w = posted[k];
+            pthread_mutex_lock(&w->mu);
+            while (w->state != 2) pthread_cond_wait(&w->cv, &w->mu);
+            w->state = 0;
+            pthread_mutex_unlock(&w->mu);
+        } else { bind_share(k); fn(k); }             /* no thread: one after the other */
     }
     t_dev = &g_state0;
-    if (have_cur) (void) hipSetDevice(cur);
+    if (have_cur) {
+        int now = -1;
+        if (hipGetDevice(&now) != hipSuccess || now != cur) { (void) hipGetLastError(); (void) hipSetDevice(cur); }
+    }
 }
 
 extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
@@ -2309,7 +2381,7 @@ extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
     size_t D = g_devices.size();
     if (D > n) D = n ? n : 1;
     M->parts.resize(D);
-    if (D == 1) { M->parts[0].staged = core1_stage(n, jobs); return M; }
+    if (D == 1) { for_each_share(M, [&](size_t) { M->parts[0].staged = core1_stage(n, jobs); }); return M; }
     for (unsigned i = 0; i < n; i++) M->parts[i % D].idx.push_back(i);       /* round robin, SURVEY 8e */
     for (size_t k = 0; k < D; k++) {
         MultiStaged::Part &P = M->parts[k];
@@ -2327,6 +2399,7 @@ extern "C" void fa_core_unstage(void *h)
     MultiStaged *M = (MultiStaged *) h;
     if (!M) return;
     for_each_share(M, [&](size_t k) { core1_unstage(M->parts[k].staged); });
+    if (M->up_host) (void) hipHostFree(M->up_host);
     delete M;
 }
 
@@ -2334,7 +2407,7 @@ extern "C" int fa_core_submit(void *h)
 {
     MultiStaged *M = (MultiStaged *) h;
     if (!M) return 0;
-    if (M->parts.size() == 1) return core1_submit(M->parts[0].staged);
+    if (M->parts.size() == 1) { int r = 0; for_each_share(M, [&](size_t) { r = core1_submit(M->parts[0].staged); }); return r; }
     int ok = 1;
     for (size_t k = 0; k < M->parts.size(); k++)                               /* inputs as the caller has them now */
         for (size_t j = 0; j < M->parts[k].idx.size(); j++) {
@@ -2352,7 +2425,7 @@ extern "C" int fa_core_finish2(void *h, int resubmit)
 {
     MultiStaged *M = (MultiStaged *) h;
     if (!M) return 0;
-    if (M->parts.size() == 1) return core1_finish2(M->parts[0].staged, resubmit);
+    if (M->parts.size() == 1) { int r = 0; for_each_share(M, [&](size_t) { r = core1_finish2(M->parts[0].staged, resubmit); }); return r; }
     for_each_share(M, [&](size_t k) { M->parts[k].good = core1_finish2(M->parts[k].staged, resubmit); });
     int good = 0;
     for (size_t k = 0; k < M->parts.size(); k++) {
@@ -2370,18 +2443,46 @@ extern "C" int fa_core_run(void *h)
     return fa_core_finish(h);
 }
 
-/* replacement inputs for a staged batch (a stream of batches over PCIe): one device only -- with several
- * the caller stages the next batch instead (fiasco_amd_batch_upload() says so) */
+/* replacement inputs for a staged batch (a stream of batches over PCIe).  The caller fills ONE pinned buffer with
+ * the planes of all frames; every share then copies the planes of ITS frames to its device (core1_upload_commit).
+ * With several shares the buffer belongs to the batch (portable pinned memory: every device reads it). */
 extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
 {
     MultiStaged *M = (MultiStaged *) h;
-    return M && M->parts.size() == 1 ? core1_upload_buffer(M->parts[0].staged, bytes) : nullptr;
+    if (!M) return nullptr;
+    if (M->parts.size() == 1) {
+        int16_t *r = nullptr;
+        for_each_share(M, [&](size_t) { r = core1_upload_buffer(M->parts[0].staged, bytes); });
+        return r;
+    }
+    /* the previous uploads have left the buffer long ago (a whole pass lies in between); make sure */
+    for_each_share(M, [&](size_t k) { Staged *S = (Staged *) M->parts[k].staged; if (S && S->ustream) (void) hipStreamSynchronize(S->ustream); });
+    if (bytes > M->up_host_bytes) {
+        if (M->up_host) (void) hipHostFree(M->up_host);
+        M->up_host = nullptr; M->up_host_bytes = 0;
+        if (hipHostMalloc((void **) &M->up_host, bytes, hipHostMallocPortable) != hipSuccess) { M->up_host = nullptr; (void) hipGetLastError(); return nullptr; }
+        M->up_host_bytes = bytes;
+    }
+    for (size_t k = 0; k < M->parts.size(); k++) {
+        Staged *S = (Staged *) M->parts[k].staged;
+        if (!S || !S->ok) return nullptr;
+        if (S->up_host && !S->up_host_shared) (void) hipHostFree(S->up_host);
+        S->up_host = M->up_host; S->up_host_bytes = M->up_host_bytes; S->up_host_shared = true;
+    }
+    return (int16_t *) M->up_host;
 }
 
 extern "C" int fa_core_upload_commit(void *h)
 {
     MultiStaged *M = (MultiStaged *) h;
-    return M && M->parts.size() == 1 ? core1_upload_commit(M->parts[0].staged) : 0;
+    if (!M) return 0;
+    if (M->parts.size() == 1) { int r = 0; for_each_share(M, [&](size_t) { r = core1_upload_commit(M->parts[0].staged); }); return r; }
+    for (size_t k = 0; k < M->parts.size(); k++)                               /* the new images of the caller's jobs */
+        for (size_t j = 0; j < M->parts[k].idx.size(); j++) M->parts[k].sub[j].image = M->jobs[M->parts[k].idx[j]].image;
+    for_each_share(M, [&](size_t k) { M->parts[k].good = core1_upload_commit(M->parts[k].staged); });
+    int ok = 1;
+    for (size_t k = 0; k < M->parts.size(); k++) ok = ok && M->parts[k].good;
+    return ok;
 }
 
 extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)

@@ -691,7 +691,7 @@ int fiasco_amd_batch_upload(fiasco_amd_batch_t *b, const unsigned char *const *p
     buf = fa_core_upload_buffer(b->staged, total * sizeof(int16_t));
     if (!buf) {
         free(off); free(nims);
-        fa_set_error("No staging memory for %.1f MiB of frames (replacing staged inputs needs a single device).",
+        fa_set_error("No staging memory for %.1f MiB of frames.",
                      total * 2 / 1048576.0);
         return 0;
     }
@@ -772,3 +772,6 @@ int fiasco_amd_encode_batch(unsigned n, const unsigned char *const *pnm, const s
     fiasco_amd_batch_free(b);
     return good;
 }
+
+/* include/libfiasco_amd_hip.h: which hot-path backend this library was linked with (the seam fa_core_*()) */
+const char *fiasco_amd_core_name(void) { return fa_core_name(); }

@@ -66,7 +66,7 @@ int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int nar
 /* name of the hot-path backend linked into this library: "hip-gfx950" for the product,
  * "oracle-cpu" for the test-only oracle library (reference seam: codec/approx.h:24-27,
  * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */
-const char *fa_core_name(void);
+const char *fiasco_amd_core_name(void);
 
 /* Devices.  Frames are independent units: every batch entry -- fiasco_amd_encode_batch(),
  * the staged batches, fiasco_coder() on an all-intra stream or a video (its groups of pictures) -- spreads

@@ -65,16 +65,25 @@ def cpu_baseline(frame_pnm, w, h):
         if not os.path.exists(exe):
             continue
         try:
-            t0 = time.time()
-            r = subprocess.run([exe, "--progress-meter", "0", "-o", out, src], env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-            dt = time.time() - t0
+            # one warm-up run, then the median of five
+            times = []
+            r = None
+            for i in range(6):
+                t0 = time.time()
+                r = subprocess.run([exe, "--progress-meter", "0", "-o", out, src], env=env,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+                if r.returncode != 0:
+                    break
+                if i:
+                    times.append(time.time() - t0)
+            dt = sorted(times)[len(times) // 2] if times else None
         except Exception:
             continue
-        if r.returncode == 0 and os.path.exists(out):
+        if r is not None and r.returncode == 0 and dt and os.path.exists(out):
             md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
             res = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": kind,
-                   "sample": "1 frame %dx%d gray, -q 20 -z 0, %.1f s, stream md5 %s" % (w, h, dt, md5[:12])}
+                   "sample": "1 frame %dx%d gray, -q 20 -z 0: median of %d runs after a warm-up, %.2f s (min %.2f, max %.2f), "
+                             "stream md5 %s" % (w, h, len(times), dt, min(times), max(times), md5[:12])}
             # SURVEY 8d also asks for "all cores, one frame per core": C concurrent processes of
             # the same coder, one frame each (C capped at 32 to bound host memory and time)
             try:
@@ -101,7 +110,7 @@ def pmc_traffic(frames, w, h):
     FETCH_SIZE / WRITE_SIZE, separate runs of this same command), committed under profiles/.
     Counters cannot be collected from inside the timed run; the figure is reported only for
     the workload it was measured on."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -215,6 +224,100 @@ def k4_pass(lib, nframes, rank):
             "limits": "MAXSTATES 30000, MAXLEVEL 26 (declared extension, SURVEY 8c)"}
 
 
+def k4_small_pass(lib, counts=(64, 8)):
+    """BASELINE config 4 as written -- 64 independent 3840x2160 frames -- on ONE GPU, and 8 frames: one GPU's share of
+    the job on an 8-GPU node.  Launches this small leave the chip empty: the launcher gives every frame several
+    workgroups (block-level speculation, the 1024-thread build).  Reported: rate, kernel build, workgroups per frame."""
+    import fiasco_amd
+    w, h = 3840, 2160
+    res = {}
+    frames = make_frames(w, h, [1234] + [300000 + i for i in range(max(counts) - 1)])
+    lib.L.fiasco_amd_release_memory()
+    lib.set_limits(30000, 26)
+    o = lib.cli_options()
+    try:
+        for n in counts:
+            b = fiasco_amd.Batch(lib, frames[:n], 20.0, o)
+            import torch
+            torch.cuda.synchronize()
+            lib.reset_stats()
+            t0 = time.perf_counter()
+            out = b.encode()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            st = lib.get_stats()
+            b.free()
+            ok = out is not None and all(x is not None for x in out)
+            md5 = hashlib.md5(out[0]).hexdigest() if ok else None
+            cus = 256
+            res["frames_%d" % n] = {
+                "frames": n, "all_encoded": ok, "seconds": dt, "frames_per_s": n / dt if ok else None,
+                "kernel_seconds": st.kernel_ms / 1e3, "launches": int(st.launches),
+                "frames_with_several_workgroups": int(st.spec_frames),
+                "workgroups_per_frame": int(lib.L.fiasco_amd_spec_workgroups(n, cus, 1, 0, 1)) or 1,
+                "kernel_build": "fiasco_frame_kernel_spec_wide" if st.spec_frames else "fiasco_frame_kernel_wide / _wide_tri",
+                "frames_by_kernel_build": list(st.frames_by_build),
+                "parity": ("frame 0 == patched reference (%s)" % md5[:12]) if md5 == REF_MD5_SEED1234[(w, h)] else "MISMATCH: %s" % md5}
+    finally:
+        o.delete()
+        lib.set_limits(6000, 22)
+        lib.L.fiasco_amd_release_memory()
+    return res
+
+
+REF_MD5_K1080 = "ca81b603e331985870426d8257eaacbd"          # patched reference, k1080.ppm at -z 0 (SURVEY App. C; tests/golden/MANIFEST_BIG.json)
+
+
+def _colour_frame(args):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    w, h, seed = args
+    return synth.ppm_bytes(synth.synth_color_k(w, h, seed))
+
+
+def config3_pass(lib, nframes):
+    """BASELINE config 3 as a throughput figure: `nframes` independent 1920x1080 colour frames (SURVEY App. C
+    k-generator, one seed each; Y, Cb, Cr bands, chroma dictionary 40) at the CLI defaults, which need the declared
+    limits extension (> 6000 states per frame, SURVEY finding 7).  Frame 0 is k1080.ppm (patched reference: ca81b603...)."""
+    import multiprocessing as mp
+    import fiasco_amd
+    w, h = 1920, 1080
+    tg = time.perf_counter()
+    with mp.get_context("fork").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        frames = pool.map(_colour_frame, [(w, h, 1234 if i == 0 else 400000 + i) for i in range(nframes)], chunksize=2)
+    t_gen = time.perf_counter() - tg
+    lib.L.fiasco_amd_release_memory()
+    lib.set_limits(30000, 26)
+    o = lib.cli_options()
+    try:
+        b = fiasco_amd.Batch(lib, frames, 20.0, o)
+        import torch
+        torch.cuda.synchronize()
+        lib.reset_stats()
+        t0 = time.perf_counter()
+        out = b.encode()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = lib.get_stats()
+        b.free()
+    finally:
+        o.delete()
+        lib.set_limits(6000, 22)
+        lib.L.fiasco_amd_release_memory()
+    ok = out is not None and all(x is not None for x in out)
+    md5 = hashlib.md5(out[0]).hexdigest() if ok else None
+    alg = float(st.bytes_mp + st.bytes_img + st.bytes_gram)
+    ks = st.kernel_ms / 1e3
+    return {"workload": "%d independent 1920x1080 colour frames, cfiasco defaults, limits extension" % nframes,
+            "all_encoded": ok, "seconds": dt, "frames_per_s": nframes / dt if ok else None,
+            "kernel_seconds": ks, "launches": int(st.launches), "reencoded_frames": int(st.reencodes),
+            "frames_by_kernel_build": list(st.frames_by_build), "states_max": int(st.states_max),
+            "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9 if ks else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": None},
+            "parity": ("frame 0 == patched reference (%s)" % md5[:12]) if md5 and md5.startswith(REF_MD5_K1080) else "MISMATCH: %s" % md5,
+            "generate_seconds": t_gen}
+
+
 REF_MD5_CONFIG5_300 = "714a25c639d8daae598f84095f4856f7"     # the real reference's stream of these 300 inputs (68 min on one core)
 
 
@@ -249,7 +352,14 @@ def config5_pass(lib, nframes):
         import shutil
         shutil.rmtree(td, ignore_errors=True)
     md5 = hashlib.md5(data).hexdigest() if ok else None
+    alg = float(st.bytes_mp + st.bytes_img + st.bytes_gram)
+    ks5 = st.kernel_ms / 1e3
     return {"workload": "%d frames 1280x720 colour, ippppppppp, --prediction, fiasco_coder() file to file" % nframes,
+            # the same byte formulas summed by the device coder over all launches of the sequence / the
+            # HIP-event time of those launches; kernel fiasco_frame_kernel_big_wide (30 frames x 8 workgroups per launch)
+            "roofline": {"bound": "hbm", "achieved": alg / ks5 / 1e9 if ks5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / ks5 / 1e9 / HBM_PEAK_GBS if ks5 else None, "traffic": None,
+                         "kernel": "fiasco_frame_kernel_big_wide", "algorithmic_bytes": alg},
             "all_encoded": ok, "seconds": dt, "frames_per_s": nframes / dt if ok else None, "bytes": len(data),
             "kernel_seconds": st.kernel_ms / 1e3, "launches": int(st.launches), "reencoded_frames": int(st.reencodes),
             "workgroups_per_frame_for_tables": int(st.coop_workgroups), "frames_decoded_on_device": int(st.decoder_frames),
@@ -318,6 +428,9 @@ def main():
                          "--width 3840 --height 2160 --frames-per-gpu 64 on 1/2/4/8 GPUs)")
     ap.add_argument("--k4-frames", type=int, default=256,
                     help="frames of the extra 3840x2160 pass (BASELINE config 4 on one GPU; 0 = skip)")
+    ap.add_argument("--config3-frames", type=int, default=256,
+                    help="frames of the extra 1920x1080 COLOUR pass (BASELINE config 3 as a batch; 0 = skip)")
+    ap.add_argument("--no-k4-small", action="store_true", help="skip the 64- and 8-frame 4K launches (BASELINE config 4 as written)")
     ap.add_argument("--config5-frames", type=int, default=300,
                     help="frames of the extra 1280x720 colour video pass (BASELINE config 5 on one GPU; 0 = skip)")
     a = ap.parse_args()
@@ -478,9 +591,13 @@ def main():
             assert all(out2[j] == out[(j + k) % F] for j in range(0, F, max(1, F // 64))), \
                 "pipelined pass did not encode the uploaded frames"
         batch.free()
-        small = k4 = c5 = None
+        small = k4 = c5 = c3 = k4s = None
         if rank == 0 and world == 1 and a.k4_frames > 0 and (a.width, a.height) == (1920, 1080):
             k4 = k4_pass(lib, a.k4_frames, rank)
+        if rank == 0 and world == 1 and not a.no_k4_small and (a.width, a.height) == (1920, 1080):
+            k4s = k4_small_pass(lib)
+        if rank == 0 and world == 1 and a.config3_frames > 0 and (a.width, a.height) == (1920, 1080):
+            c3 = config3_pass(lib, a.config3_frames)
         if rank == 0 and world == 1 and a.config5_frames > 0 and (a.width, a.height) == (1920, 1080):
             c5 = config5_pass(lib, a.config5_frames)
         if rank == 0 and world == 1 and not a.no_small_launches and (a.width, a.height) == (1920, 1080):
@@ -551,6 +668,10 @@ def main():
                        # target: >= 50 frames/s on one GPU)
                        "k4_frames_per_s": (k4 or {}).get("frames_per_s") if not dry else None,
                        "k4": k4 if not dry else None,
+                       # BASELINE config 4 as written: 64 frames on this GPU, and 8 (one GPU's share on an 8-GPU node)
+                       "k4_64": k4s if not dry else None,
+                       # BASELINE config 3 as a batch: 1080p colour at the CLI defaults (limits extension)
+                       "config3": c3 if not dry else None,
                        # BASELINE config 5's workload on this GPU (north-star row F3/F4: motion search, prediction, decoder)
                        "config5": c5 if not dry else None,
                        # launches that leave the chip empty: several workgroups per frame (speculation)

@@ -17,18 +17,18 @@ mkdir -p $O
 cd /tmp
 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 > $O/bench_traced.json 2> $O/trace.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 --config3-frames 0 --no-k4-small > $O/bench_traced.json 2> $O/trace.err
 python3 $R/profiles/summarize_rocpd.py $O/trace/*_results.db > $O/kernel_trace_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 > $O/bench_pmc_$c.json 2> $O/pmc_$c.err
+  timeout 400 rocprofv3 --pmc $c -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 --config3-frames 0 --no-k4-small > $O/bench_pmc_$c.json 2> $O/pmc_$c.err
   python3 $R/profiles/summarize_rocpd.py $O/pmc_$c/*_results.db > $O/pmc_$c.txt 2>&1
 done
-timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/pmc_tcc -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 > $O/bench_pmc_tcc.json 2> $O/pmc_tcc.err
+timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/pmc_tcc -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 --config3-frames 0 --no-k4-small > $O/bench_pmc_tcc.json 2> $O/pmc_tcc.err
 python3 $R/profiles/summarize_rocpd.py $O/pmc_tcc/*_results.db > $O/pmc_tcc.txt 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 > $O/bench_pmc_sq.json 2> $O/pmc_sq.err
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 --config3-frames 0 --no-k4-small > $O/bench_pmc_sq.json 2> $O/pmc_sq.err
 python3 $R/profiles/summarize_rocpd.py $O/pmc_sq/*_results.db > $O/pmc_sq.txt 2>&1
 # 4K: 256 frames in one launch through the frame queue (HBM holds about 130 of the 2.2 GB slabs of the tight capacity guess)
-timeout 900 python3 $R/bench.py --width 3840 --height 2160 --frames-per-gpu 256 --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 > $O/bench_4k.json 2> $O/bench_4k.err
+timeout 900 python3 $R/bench.py --width 3840 --height 2160 --frames-per-gpu 256 --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-loop --no-small-launches --k4-frames 0 --config5-frames 0 --config3-frames 0 --no-k4-small > $O/bench_4k.json 2> $O/bench_4k.err
 # small launches: several workgroups per frame (block-level speculation): kernel trace of 16 x 1080p and 1 x 4K
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_spec -o kt -- python3 $R/tests/gpu_spec_batch.py 1920 1080 16 default > $O/spec_16x1080p.txt 2> $O/trace_spec.err
 python3 $R/profiles/summarize_rocpd.py $O/trace_spec/*_results.db > $O/spec_kernel_trace_stats.txt 2>&1

@@ -74,6 +74,9 @@ extern "C" void fc_launch_big_wide(DevFrame *d_frames, unsigned n, unsigned nlen
 /* the 512-thread big build with coefficient models of up to 512 symbols per context (frame_coder.h FC_HM) */
 extern "C" void fc_launch_big_hm(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
+/* ... and with the other models of the reference's registries (frame_coder.h FC_GM) */
+extern "C" void fc_launch_big_gm(DevFrame *d_frames, unsigned n, unsigned nlend, unsigned long long *ring, unsigned *ctr,
+                       const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 
 /* block-level speculation (frame_coder.h, FcSpecCtl): n frames with G workgroups each */
 extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
@@ -107,6 +110,16 @@ static size_t bx_bytes(const fa_wfa *w) { return 16 + (size_t) w->basis_states *
 static bool needs_hm_variant(const fa_cparams *cp)
 {
     return cp->rpf.mantissa_bits > 5 || cp->dc_rpf.mantissa_bits > 5 || cp->d_rpf.mantissa_bits > 5 || cp->d_dc_rpf.mantissa_bits > 5;
+}
+
+/* models other than the `rle' pools and the `adaptive' coefficients that fiasco.h can ask for
+ * (fiasco_amd_c_options_set_models; the delta set counts when it is used: prediction, P / B frames): the FC_GM build */
+static bool needs_gm_variant(const fa_job *job)
+{
+    const fa_cparams *cp = &job->cp;
+    const bool delta_used = cp->prediction || job->frame_type != FA_I_FRAME;
+    return cp->pool_kind != FA_POOL_RLE || cp->coeff_kind != FA_COEFF_ADAPTIVE
+           || (delta_used && (cp->d_pool_kind != FA_POOL_RLE || cp->d_coeff_kind != FA_COEFF_ADAPTIVE));
 }
 
 static bool needs_big_variant(const fa_cparams *cp, const fa_wfa *basis)
@@ -559,13 +572,14 @@ struct Layout {
     size_t mv, past, future, mc_fwd, mc_bwd, pix_chroma;                    /* P frames only */
     size_t coop;                                                            /* FcCoop: header + the block's pixels */
     size_t bx;                                                              /* DevFrame.bx: rows of a long basis */
+    size_t gq, lginv;                                                       /* FC_GM build: DevFrame.gq, DevFrame.lginv */
     int    max_save;
 };
 
 /* P: capacity for states with tables; PA >= P: capacity of the automaton arrays (chroma
  * states of a colour frame never own tables) */
 static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il, int low, size_t npix,
-                          int max_save, int inter, int plevels, int color, bool tri, bool hm)
+                          int max_save, int inter, int plevels, int color, bool tri, bool hm, int gm_states = 0)
 {
     Layout L;
     memset(&L, 0, sizeof L);             /* compared with memcmp (frame queue) */
@@ -624,6 +638,8 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
     CARVE(pix_chroma, inter && color ? npix / 3 * 2 * 2 : 0);
     CARVE(coop, FC_COOP_HDR + ((size_t) (NS + 1) << il) * 4);
     CARVE(bx, FC_BX_BYTES);
+    CARVE(gq, gm_states ? (size_t) FC_GQ_SLOTS * P * 2 : 0);
+    CARVE(lginv, gm_states ? ((size_t) gm_states + 2) * 8 : 0);
     CARVE(pix16, npix * 2);
 #undef CARVE
     L.total = o;
@@ -673,20 +689,8 @@ static int device_supported(const fa_job *job, char *why, size_t n)
             if (e >= w->basis_states * 12) { snprintf(why, n, "edge lists of the initial basis run on into the coder's states"); return 0; }
         }
     }
-    /* the models fiasco.h can ask for -- and only those -- run on the device: `rle' pools, `adaptive'
-     * coefficients (the `constant' pool is the delta pool of a plain I frame and is never searched).  The
-     * others of the reference's registries exist in the CPU oracle only (no setter in fiasco.h reaches them,
-     * codec/options.c:77-80); never a silent CPU path: refused */
-    {
-        const bool delta_used = cp->prediction || job->frame_type != FA_I_FRAME;
-        if (cp->pool_kind != FA_POOL_RLE || (delta_used && cp->d_pool_kind != FA_POOL_RLE)
-            || cp->coeff_kind != FA_COEFF_ADAPTIVE || (delta_used && cp->d_coeff_kind != FA_COEFF_ADAPTIVE)) {
-            snprintf(why, n, "the device coder runs the `rle' domain pool and the `adaptive' coefficient model only "
-                             "(asked for: %s / %s, %s / %s)", fa_pool_name(cp->pool_kind), fa_pool_name(cp->d_pool_kind),
-                     fa_coeff_name(cp->coeff_kind), fa_coeff_name(cp->d_coeff_kind));
-            return 0;
-        }
-    }
+    /* (every entry of the reference's model registries runs on the device since round 5: the `rle' pools and the
+     * `adaptive' coefficients of fiasco.h in the fast builds, the others in the FC_GM build) */
     return 1;
 }
 
@@ -702,6 +706,8 @@ struct FrameSlot {
     DevFrame F;
     bool     staged = false, done = false, big = false, rejected = false;
     bool     hm = false;         /* coefficient models of more than 64 symbols per context: the FC_HM kernel build */
+    bool     gm = false;         /* models beyond rle / adaptive: the FC_GM kernel build */
+    std::vector<double> lginv_host;      /* upload source of DevFrame.lginv */
     bool     wide_only = false;  /* default geometry, but beyond the 256-thread build's LDS pools */
     bool     tri = false;        /* triangular Gram tables (half the slab; the wide_tri build of the kernel) */
     bool     borrow = false;     /* no slab of its own: encoded in the slab of a queue workgroup */
@@ -921,6 +927,10 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.coeff_nt = F.lc_max - F.lc_min + 2;
     F.basis_states = (int) w->basis_states;
     F.bx = bxl ? (const int *) (base + L.bx) : nullptr;
+    F.gm_pool[0] = (int) cp->pool_kind; F.gm_pool[1] = (int) cp->d_pool_kind;
+    F.gm_coeff[0] = (int) cp->coeff_kind; F.gm_coeff[1] = (int) cp->d_coeff_kind;
+    F.gq = fs.gm ? (int16_t *) (base + L.gq) : nullptr;
+    F.lginv = fs.gm ? (const double *) (base + L.lginv) : nullptr;
     for (unsigned s = 0; s < (bxl ? 0u : w->basis_states); s++) {
         F.b_final[s] = w->final_distribution[s];
         F.b_dtype[s] = w->domain_type[s];
@@ -1000,7 +1010,8 @@ static void slot_layout(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm || fs.gm,
+                       fs.gm ? (int) cp->limit_states : 0);
 }
 
 /* ---- frame queue: which frames may share slabs ---- */
@@ -1009,7 +1020,7 @@ static bool queue_eligible(const Staged *S, const FrameSlot &fs)
 {
     const fa_job *job = &S->jobs[fs.job];
     /* inputs of P/B frames and the carried y_column of a colour stream live inside the slab */
-    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !long_basis(job->wfa) && !fs.hm && !fa_knob("FIASCO_AMD_NO_QUEUE");
+    return job->frame_type == FA_I_FRAME && !job->ycol_carry && !fs.spec && !long_basis(job->wfa) && !fs.hm && !fs.gm && !fa_knob("FIASCO_AMD_NO_QUEUE");
 }
 
 /* same geometry, capacity and coder parameters as the queue's first frame: any of its slabs fits */
@@ -1077,7 +1088,8 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         max_save = 1 << (span < 1 ? 1 : span > 9 ? 9 : span);
     }
     fs.L = make_layout(fs.P, fs.PA, NL, NS, NA, NI, il, low, npix * bands, max_save, inter,
-                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm);
+                       (int) cp->p_max_level - (int) cp->p_min_level + 1, job->image->color ? 1 : 0, fs.tri, fs.hm || fs.gm,
+                       fs.gm ? (int) cp->limit_states : 0);
     fs.base = slab_acquire(fs.L.total, &fs.bytes);
     /* developer aid: FIASCO_AMD_POISON=<byte> fills the slab first -- the kernel must write every
      * cell before it reads it, whatever an earlier frame left there */
@@ -1088,12 +1100,13 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         return 0;
     }
     fill_frame(fs, job);
-    const int maxsym = fs.hm ? FC_MAXSYM_HM : FC_MAXSYM_STD;
-    if (fs.F.coeff_size > (fs.hm ? FC_MAXCOEFF_HM : fs.big ? FC_MAXCOEFF_BIG_STD : FC_MAXCOEFF) || fs.F.dcs > maxsym || fs.F.sy > maxsym
-        || (fs.F.pred_on && (fs.F.d_coeff_size > (fs.hm ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD) || fs.F.d_dcs > maxsym || fs.F.d_sy > maxsym))
+    const bool hmx = fs.hm || fs.gm;              /* the FC_GM build has the FC_HM build's model sizes */
+    const int maxsym = hmx ? FC_MAXSYM_HM : FC_MAXSYM_STD;
+    if (fs.F.coeff_size > (hmx ? FC_MAXCOEFF_HM : fs.big ? FC_MAXCOEFF_BIG_STD : FC_MAXCOEFF) || fs.F.dcs > maxsym || fs.F.sy > maxsym
+        || (fs.F.pred_on && (fs.F.d_coeff_size > (hmx ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD) || fs.F.d_dcs > maxsym || fs.F.d_sy > maxsym))
         || fs.F.ML > 26) {
         snprintf(job->errmsg, sizeof job->errmsg,
-                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", fs.hm ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD);
+                 "coefficient model too large for the device coder (levels x mantissa symbols > %d)", hmx ? FC_MAXCOEFF_HM : FC_MAXCOEFF_BIG_STD);
         slab_release(fs.base, fs.bytes); fs.base = nullptr;
         fs.done = true; fs.rejected = true;      /* permanent: not a matter of free HBM */
         return 0;
@@ -1140,6 +1153,16 @@ static int stage_slot(Staged *S, FrameSlot &fs)
         if (hipMemcpyAsync(fs.base + fs.L.ycol0, fs.ycol_host.data(), fs.ycol_host.size(),
                            hipMemcpyHostToDevice, S->stream) != hipSuccess) {
             snprintf(job->errmsg, sizeof job->errmsg, "HIP error: y_column upload failed");
+            slab_release(fs.base, fs.bytes); fs.base = nullptr;
+            return 0;
+        }
+    }
+    if (fs.F.lginv) {                      /* log2 (1.0 / n) as THIS host's libm gives it: uniform_bits, codec/domain-pool.c:592-615 */
+        const unsigned nmax = cp->limit_states + 1;
+        fs.lginv_host.assign(nmax + 1, 0.0);
+        for (unsigned k = 1; k <= nmax; k++) fs.lginv_host[k] = log2(1.0 / k);
+        if (hipMemcpyAsync(fs.base + fs.L.lginv, fs.lginv_host.data(), fs.lginv_host.size() * 8, hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+            snprintf(job->errmsg, sizeof job->errmsg, "HIP error: table upload failed");
             slab_release(fs.base, fs.bytes); fs.base = nullptr;
             return 0;
         }
@@ -1267,6 +1290,8 @@ static void *core1_stage(unsigned n, fa_job *jobs)
                  /* a chroma dictionary of more than 63 states: the list scan of the big builds (mp_steps_list_global) */
                  || (jobs[i].image->color && cp->chroma_max_states > 63);
         fs.hm = needs_hm_variant(cp);
+        fs.gm = needs_gm_variant(&jobs[i]) || fa_knob("FIASCO_AMD_FORCE_GM") != nullptr;     /* (tests: every frame through the FC_GM build) */
+        if (fs.gm) fs.big = true;
         fs.wide_only = !fs.big && needs_wide_variant(cp);
                 /* (experiments: FIASCO_AMD_SPEC_BUILD1 runs the speculating kernel build with ONE workgroup per frame) */
         const bool build1 = !specG && fa_knob("FIASCO_AMD_SPEC_BUILD1") != nullptr;
@@ -1310,7 +1335,7 @@ static void *core1_stage(unsigned n, fa_job *jobs)
         size_t free_b = 0, total_b = 0, pooled = 0;
         for (size_t i = 0; i < g_free.size(); i++) pooled += g_free[i].bytes;
         size_t want = S->slots.size();
-        const size_t resident = (size_t) cus * frames_per_cu(probe.big, probe.P > 12 * 256 || probe.wide_only || probe.hm);
+        const size_t resident = (size_t) cus * frames_per_cu(probe.big, probe.P > 12 * 256 || probe.wide_only || probe.hm || probe.gm);
         if (want > resident) want = resident;
         const bool hbm_bound = hipMemGetInfo(&free_b, &total_b) == hipSuccess && probe.L.total * want > free_b + pooled;
         if ((hbm_bound || S->slots.size() > resident) && queue_eligible(S, probe)) {
@@ -1366,7 +1391,7 @@ static void *core1_stage(unsigned n, fa_job *jobs)
                 S->qL = fs.L; S->qP = fs.P; S->qPA = fs.PA; S->qbig = fs.big; S->qtri = fs.tri;
                 /* workgroups the chip holds at once: frame_coder.hip FC_WG_PER_CU of the build the
                  * launch will use (wide build for P > 3072: one per CU) */
-                S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only || fs.hm);
+                S->lender_cap = (size_t) cus * frames_per_cu(fs.big, fs.P > 12 * 256 || fs.wide_only || fs.hm || fs.gm);
                 if (fa_knob("FIASCO_AMD_QUEUE_SLABS") && atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS")) > 0)
                     S->lender_cap = (size_t) atoi(fa_knob("FIASCO_AMD_QUEUE_SLABS"));     /* tests: a short queue on small batches */
             } else if (elig && queue_layout(S, fs)) S->lenders++;
@@ -1627,7 +1652,7 @@ static bool launch_wave(Staged *S)
      * {256, 512 or 1024 threads}.  The wide builds take launches with no more frames than CUs (the
      * chip cannot be filled with frames anyway: give each frame twice the lanes) and frames
      * whose state capacity exceeds the 256-thread build's register-resident scan (4K). */
-    size_t group_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, group_lend[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, group_borrow[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    size_t group_n[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, group_lend[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, group_borrow[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -1637,23 +1662,23 @@ static bool launch_wave(Staged *S)
         /* per build: first the frames of the queue's layout -- those with a slab (the queue's
          * workgroups), then those without --, then every other frame (one workgroup each) */
         std::vector<size_t> ordered;
-        for (int g = 0; g < 8; g++)
+        for (int g = 0; g < 9; g++)
             for (int part = 0; part < 3; part++)
                 for (size_t b = 0; b < batch.size(); b++) {
                     const FrameSlot &fs = S->slots[batch[b]];
                     const bool wide = few || fs.P > 12 * 256 || fs.wide_only;
-                    /* group 5: the FC_HM build; groups 6, 7: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
+                    /* group 5: the FC_HM build, 6: the FC_GM build; groups 7, 8: several workgroups per frame (FC_SPEC builds, 256 / 1024 threads) */
                     const bool spec = fs.spec && (S->specG >= 2 || fa_knob("FIASCO_AMD_SPEC_BUILD1")) && !fs.borrow && !fs.tri && !fs.big && fs.P <= 12 * 1024;
                     /* (FIASCO_AMD_SPEC_WIDE=0 / 1: experiments with the width of the workgroups) */
                     const char *sw = fa_knob("FIASCO_AMD_SPEC_WIDE");
                     const bool spec_wide = spec && (fs.P > 12 * 256 || fs.wide_only || (sw && atoi(sw) == 1));
-                    if ((spec ? (spec_wide ? 7 : 6) : fs.hm ? 5 : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
+                    if ((spec ? (spec_wide ? 8 : 7) : fs.gm ? 6 : fs.hm ? 5 : fs.tri ? 4 : (int) fs.big * 2 + (int) wide) != g) continue;
                     const bool q = S->borrowers && queue_eligible(S, fs) && queue_layout(S, fs);
                     const int where = fs.borrow ? 1 : q ? 0 : 2;
                     if (where != part) continue;
                     ordered.push_back(batch[b]);
                     group_n[g]++;
-                    if (g < 5) g_stats.frames_by_build[g]++; else if (g == 5) g_stats.frames_by_build[3]++; else g_stats.spec_frames++;
+                    if (g < 5) g_stats.frames_by_build[g]++; else if (g <= 6) g_stats.frames_by_build[3]++; else g_stats.spec_frames++;
                     if (part == 0) group_lend[g]++; else if (part == 1) group_borrow[g]++;
                 }
         batch.swap(ordered);
@@ -1698,21 +1723,21 @@ static bool launch_wave(Staged *S)
     bool fail = false;
     S->spec_frames.clear();
     S->spec_first[0] = S->spec_first[1] = 0; S->spec_n[0] = S->spec_n[1] = 0;
-    if (group_n[6] + group_n[7] && S->specG < 2) {       /* FIASCO_AMD_SPEC_BUILD1: the build alone */
-        const size_t nall = group_n[6] + group_n[7], first_all = batch.size() - nall;
-        S->spec_first[0] = first_all; S->spec_n[0] = group_n[6];
-        S->spec_first[1] = first_all + group_n[6]; S->spec_n[1] = group_n[7];
+    if (group_n[7] + group_n[8] && S->specG < 2) {       /* FIASCO_AMD_SPEC_BUILD1: the build alone */
+        const size_t nall = group_n[7] + group_n[8], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[7];
+        S->spec_first[1] = first_all + group_n[7]; S->spec_n[1] = group_n[8];
         for (size_t i = 0; i < nall; i++) hf[first_all + i].spec = nullptr;
-    } else if (group_n[6] + group_n[7]) {
+    } else if (group_n[7] + group_n[8]) {
         /* the speculating frames (groups 5 and 6: 256 / 1024 threads per workgroup; they are the last of
          * the batch): control block + checkpoint slots + block list + table ring per frame, then per
          * verifier workgroup its private <sub-block, state> tables, scan scratch and pool list; verifier
          * v of a frame owns the state ids [P - 16 v, P - 16 (v - 1)) */
         const int G = S->specG;
         const int T = spec_workers(G), NV = G - 1 - T;           /* table workers, verifiers */
-        const size_t nall = group_n[6] + group_n[7], first_all = batch.size() - nall;
-        S->spec_first[0] = first_all; S->spec_n[0] = group_n[6];
-        S->spec_first[1] = first_all + group_n[6]; S->spec_n[1] = group_n[7];
+        const size_t nall = group_n[7] + group_n[8], first_all = batch.size() - nall;
+        S->spec_first[0] = first_all; S->spec_n[0] = group_n[7];
+        S->spec_first[1] = first_all + group_n[7]; S->spec_n[1] = group_n[8];
         /* one span for every frame of the launch (sized for the largest) */
         size_t max_blocks = 0, max_tab = 0, max_slot = 0;
         std::vector<std::vector<uint16_t>> lists(nall);
@@ -1722,7 +1747,7 @@ static bool launch_wave(Staged *S)
             if (lists[i].size() / 2 > max_blocks) max_blocks = lists[i].size() / 2;
             const size_t tab = align_up(((size_t) F.NS + (size_t) F.NA) * (size_t) F.P * 4, 256);
             if (tab > max_tab) max_tab = tab;
-            const size_t slot = i < group_n[6] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
+            const size_t slot = i < group_n[7] ? fc_spec_slot_bytes() : fc_spec_slot_bytes_wide();
             if (slot > max_slot) max_slot = slot;
         }
         const size_t off_blocks = align_up((size_t) fc_spec_ctl_bytes() + (size_t) 2 * FC_SPEC_W * max_slot, 256);      /* checkpoint + result slots */
@@ -1819,7 +1844,7 @@ static bool launch_wave(Staged *S)
         /* bound of a queued frame's wait for a slab (frame_coder.hip); tests shorten it */
         unsigned long long qwait = FC_QUEUE_WAIT_TICKS;
         if (fa_knob("FIASCO_AMD_QUEUE_WAIT_MS")) qwait = 100000ull * (unsigned long long) atoll(fa_knob("FIASCO_AMD_QUEUE_WAIT_MS"));
-        static const launch_fn launch[6] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri, fc_launch_big_hm };
+        static const launch_fn launch[7] = { fc_launch, fc_launch_wide, fc_launch_big, fc_launch_big_wide, fc_launch_wide_tri, fc_launch_big_hm, fc_launch_big_gm };
         size_t first = 0;
         for (int k = 0; k < 2 && !fail; k++) {
             if (!S->spec_n[k]) continue;
@@ -1830,7 +1855,7 @@ static bool launch_wave(Staged *S)
             (k ? fc_launch_spec_wide : fc_launch_spec)(S->d_frames + S->spec_first[k], vfr, (unsigned) S->spec_n[k],
                                                        on ? (unsigned) S->specG : 1u, S->stream);
         }
-        for (int g = 0; g < 6 && !fail; g++) {
+        for (int g = 0; g < 7 && !fail; g++) {
             size_t plain = group_n[g], at = first;
             if (group_borrow[g]) {
                 /* the queue: group_lend[g] frames with slabs first, then the frames that borrow one */

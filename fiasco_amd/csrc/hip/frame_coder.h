@@ -47,6 +47,18 @@
 #ifndef FC_HM
 #define FC_HM 0
 #endif
+/* FC_GM: the "generic models" build (the FC_HM build + the other entries of the reference's model registries,
+ * codec/domain-pool.c:188-236 and codec/coeff.c:97-131: `adaptive', `basis', `uniform', `rle-no-chroma' and
+ * `constant' domain pools, `uniform' coefficients; no setter of fiasco.h reaches them, fiasco_amd_c_options_set_models
+ * does).  The candidate scan is the list scan with scratch in HBM; prices and model updates follow the kind of the
+ * ACTIVE model set (csrc/hip/mp_device.inc, `#if FC_GM'). */
+#ifndef FC_GM
+#define FC_GM 0
+#endif
+/* DevFrame.gm_pool[] / gm_coeff[]: fa_pool_kind / fa_coeff_kind of csrc/host/fa_host.h */
+enum { FC_PK_ADAPTIVE = 0, FC_PK_CONSTANT = 1, FC_PK_BASIS = 2, FC_PK_UNIFORM = 3, FC_PK_RLE = 4, FC_PK_RLE_NO_CHROMA = 5 };
+enum { FC_CK_ADAPTIVE = 0, FC_CK_UNIFORM = 1 };
+#define FC_GQ_SLOTS (2 + FC_MAXDEPTH_BIG * 5)   /* DevFrame.gq: two current arrays + five snapshots per depth */
 #define FC_MAXCOEFF_BIG_STD 640     /* big builds: 9 levels x 64 symbols + 64 (mantissas up to 5 bits) */
 #define FC_MAXSYM_STD   64          /* symbols per context (mantissa <= 5) */
 #define FC_MAXCOEFF_HM  5120        /* FC_HM: 9 levels x 512 symbols + 512 (mantissas up to 8 bits) */
@@ -126,6 +138,13 @@ typedef struct DevFrame {
      * builds only.  Words: [0] basis states nb, [1] row entries n = 12 nb + 12, [2..3] 0; float final[nb];
      * int domain_type[nb]; float weight[n]; int16 into[n].  null: the basis is in b_tree .. b_dtype. ---- */
     const int *bx;
+    /* ---- FC_GM build: model kinds of the normal [0] and the delta [1] set; gq: the probability indices of the
+     * quasi-arithmetic pools (qac_model_t.index, codec/domain-pool.c:259-274), FC_GQ_SLOTS arrays of P int16 -- [0]
+     * and [1] the current ones of the two sets, the rest the snapshots of the partition search (model_duplicate);
+     * lginv[n] = log2(1.0 / n) as the HOST's libm gives it (uniform_bits, :592-615), n <= limit_states ---- */
+    int      gm_pool[2], gm_coeff[2];
+    int16_t *gq;
+    const double *lginv;
     /* ---- tables ---- */
     const int16_t *pix16;
     float   *gram, *diag, *ipis, *d5, *img, *imgT, *norms;

@@ -72,8 +72,15 @@
 #if FC_HM && !(FC_VARIANT_BIG && FC_VARIANT_WIDE)
 #error "FC_HM is a variant of the 512-thread big build"
 #endif
+#if FC_GM && !FC_HM
+#error "FC_GM is a variant of the FC_HM build"
+#endif
 #if FC_VARIANT_BIG
-#if FC_HM
+#if FC_GM
+#define FC_KERNEL    fiasco_frame_kernel_big_gm
+#define FC_LAUNCH    fc_launch_big_gm
+#define FC_OCCUPANCY fc_occupancy_big_gm
+#elif FC_HM
 #define FC_KERNEL    fiasco_frame_kernel_big_hm
 #define FC_LAUNCH    fc_launch_big_hm
 #define FC_OCCUPANCY fc_occupancy_big_hm
@@ -268,6 +275,9 @@ struct MPState {
     const float *numrow;         /* <range, state> row of the call: ipis slot, d5 or d4 address */
     short excl[MAXED + 1];       /* list positions excluded from this run, NOEDGE terminated */
 #endif
+#if FC_GM
+    short kq[MAXED + 1];         /* quasi-arithmetic pools: probability index of the kept vectors' positions */
+#endif
     /* per-step uniform parts of the stage-1 position pricing (mp_device.inc, StepCtx) */
     float s1_pre[MAXED], s1_sfx[MAXED], s1_z0, s1_zy;
     int   s1_last[MAXED], s1_k[MAXED], s1_thr[MAXED];
@@ -422,6 +432,12 @@ struct Sh {
         uint16_t *at_x, *at_y; int color;
         float rpf_range, dc_range;
     } par;
+#if FC_GM
+    /* generic models (frame_coder.h FC_GM): kinds of the ACTIVE [0] and the resting [1] model set (pool, coefficients),
+     * which of the two current probability-index arrays of DevFrame.gq is the active set's, and -- per call of the
+     * matching pursuit -- the price of the empty domain list, of the kept vectors of the running step, log2(1 / n) */
+    struct { int pk[2], ck[2], qa; float base, kept; double lg1; int16_t *gq; int P; } gm;
+#endif
     int      states;               /* wfa->states */
     int      flim;                 /* Gram tables: states below it have mirrored entries */
     int      failed;
@@ -466,6 +482,14 @@ struct Sh {
     } sl;
 #endif
 };
+#if FC_GM
+/* generic models: kinds, and the probability-index arrays of the quasi-arithmetic pools in DevFrame.gq */
+#define GM_QAC(k)   ((k) == FC_PK_ADAPTIVE || (k) == FC_PK_BASIS)
+#define GM_RLE(k)   ((k) == FC_PK_RLE || (k) == FC_PK_RLE_NO_CHROMA)
+#define GQ_CUR(sh, set)          ((sh).gm.gq + (size_t) ((sh).gm.qa ^ (set)) * (sh).gm.P)       /* set 0: active, 1: resting */
+#define GQ_SNAP(sh, depth, slot) ((sh).gm.gq + (size_t) (2 + (depth) * 5 + (slot)) * (sh).gm.P)
+/* snapshot slots of a depth: 0 pool0, 1 pool_lc, 2 dpool0, 3 pool_rec, 4 dpool_rec (SFrame) */
+#endif
 #if FC_SPEC
 #define DEAD(sh, s) ((unsigned) ((int) (s) - (sh).gap_lo) < (unsigned) ((sh).gap_hi - (sh).gap_lo))
 #else
@@ -1500,7 +1524,17 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     if (tid == 0) { sh.lc_min = F.ML; sh.ystates = states; }
     /* chroma dictionaries of more than 63 states (cfiasco --chroma-dictionary 64 ..; big builds): the list does not
      * fit sh.dl / one wave -- it lives in F.pool_states, the search is mp_steps_list_global */
-    const bool longl = FC_VARIANT_BIG && maxd > 63;
+    const bool longl = FC_GM || (FC_VARIANT_BIG && maxd > 63);
+#if FC_GM
+    /* default_chroma (codec/domain-pool.c:964-968): the constant, the uniform and the rle-no-chroma pool stay as they are */
+    const bool keep_pool = sh.gm.pk[0] == FC_PK_CONSTANT || sh.gm.pk[0] == FC_PK_UNIFORM || sh.gm.pk[0] == FC_PK_RLE_NO_CHROMA;
+#else
+    const bool keep_pool = false;
+#endif
+    const int oldn = (int) m.n;
+    (void) oldn;
+    if (keep_pool) {
+    } else
     if (longl && maxd < (int) m.n) {
         uint8_t *const mark = F.used;                     /* [P] scratch of the general scan: free between the bands */
         for (int d = tid; d < to; d += B) { __hip_atomic_store(&F.hits[d], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mark[d] = 0; }
@@ -1558,9 +1592,28 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
             int acc = 0;
             for (int t = 0; t < B; t++) { const int c = scr[t]; scr[t] = acc; acc += c; }
             m.n = (unsigned short) acc;
+            scr[B] = 0x7fffffff;
         }
         __syncthreads();
         int o = scr[tid];
+#if FC_GM
+        if (GM_QAC(sh.gm.pk[0])) {
+            /* qac_chroma (codec/domain-pool.c:466-498): a kept state keeps the probability index it had; through a
+             * snapshot slot nobody uses between the bands (the compaction moves entries in place) */
+            int16_t *q = GQ_CUR(sh, 0), *tmp = GQ_SNAP(sh, 0, 0);
+            /* the reference walks the old and the new list side by side (:480-486): behind the first kept state that
+             * the pool did not hold (a full pool) every index stays 0 */
+            int miss = 0x7fffffff, oo = o;
+            for (int d = lo; d < hi; d++)
+                if (mark[d]) { const int pd = F.pos[d]; if ((pd < 0 || pd >= oldn) && oo < miss) miss = oo; oo++; }
+            atomicMin(&scr[B], miss);
+            __syncthreads();
+            const int fm = scr[B];
+            for (int d = lo; d < hi; d++) if (mark[d]) { tmp[o] = o < fm ? q[F.pos[d]] : (int16_t) 0; F.pool_states[o++] = (short) d; }
+            __syncthreads();
+            for (int i = tid; i < (int) m.n; i += B) q[i] = tmp[i];
+        } else
+#endif
         for (int d = lo; d < hi; d++) if (mark[d]) F.pool_states[o++] = (short) d;
     } else if (longl) {
         /* every pool state stays in the list (F.pool_states as it is) */
@@ -1627,7 +1680,7 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
         sh.dl[tid] = F.pool_states[tid];                 /* n <= chroma_max <= 63 */
     }
     __syncthreads();
-    if (tid == 0) { m.y_index = 0; m.max_domains = m.n; }
+    if (tid == 0 && !keep_pool) { m.y_index = 0; m.max_domains = m.n; }
     for (int s = tid; s < states; s += B) F.pos[s] = -1;
     /* finest level with a linear combination in the luminance band */
     int mn = F.ML;
@@ -1693,6 +1746,10 @@ __device__ void swap_model_sets(Sh &sh)
     } else if (tid == 128) {
 #endif
         Pool t = sh.pool; sh.pool = sh.dpool; sh.dpool = t;
+#if FC_GM
+        { int k = sh.gm.pk[0]; sh.gm.pk[0] = sh.gm.pk[1]; sh.gm.pk[1] = k; k = sh.gm.ck[0]; sh.gm.ck[0] = sh.gm.ck[1]; sh.gm.ck[1] = k; }
+        sh.gm.qa ^= 1;
+#endif
     } else if (tid == 129) {
         int i; float f;
         i = sh.par.rpf_mant; sh.par.rpf_mant = sh.dq.rpf_mant; sh.dq.rpf_mant = i;
@@ -2046,7 +2103,9 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
     __syncthreads();
     if (keep) {
         /* the delta pool saw every append; the normal pool holds the same list */
+#if !FC_GM              /* (generic models: both pools were offered every state, each by its own rule -- gm_offer) */
         if (tid == 0) { sh.pool.n = sh.dpool.n; }
+#endif
         /* rows of the new states in the block's tables: zero (:342-345,481-484); their level-5
          * dots with the block are what later table updates start from */
         for (int s = fr.states + tid; s < new_states; s += B)
@@ -2119,6 +2178,68 @@ __device__ __noinline__ void op_pred_finish(DevFrame &__restrict__ F, Sh &__rest
 #endif
 #define TM_AT(sh, depth, which, ML) (SNAP_TM(sh) + ((depth) * TM_SLOTS(sh) + (which)) * TM_N16(ML))
 
+#if FC_GM
+/* ---- generic models (frame_coder.h FC_GM) ------------------------------------------------------------
+ * The two model sets keep ONE list of states (F.pool_states, F.pos) like the two `rle' pools of the other builds:
+ * every pool that keeps a list takes the states it is offered in the same order until it is full
+ * (codec/subdivide.c:571-581; rle_append codec/domain-pool.c:832-852, qac_append :448-464, default_append
+ * :957-962), so the list of a pool is the first Pool.n entries of the common one.  A `uniform' pool has no model:
+ * its list is every usable state (:578-590), Pool.n counts them; the `constant' pool is the list {0} (:518-528). */
+
+__device__ __forceinline__ float gm_m0(const Sh &sh, int idx) { return sh.m0tab[qac_shift(idx)]; }   /* matrix_0, domain-pool.c:970-999 */
+__device__ __forceinline__ float gm_m1(int idx) { return (float) qac_shift(idx); }                   /* matrix_1 */
+
+/* lane 0: n probability indices, 16 bytes at a time (the arrays are P int16 apart, P a multiple of 64) */
+__device__ void gq_copy(int16_t *dst, const int16_t *src, int n)
+{
+    const int n16 = (n + 7) / 8;
+    for (int i = 0; i < n16; i++) ((uint4 *) dst)[i] = ((const uint4 *) src)[i];
+}
+/* qac_model_duplicate (codec/domain-pool.c:318-331) beside the copy of the Pool struct: lane 0 */
+__device__ void gq_save(Sh &sh, int set, int depth, int slot)
+{
+    if (GM_QAC(sh.gm.pk[set])) gq_copy(GQ_SNAP(sh, depth, slot), GQ_CUR(sh, set), set ? sh.dpool.n : sh.pool.n);
+}
+__device__ void gq_load(Sh &sh, int set, int depth, int slot)      /* AFTER the Pool struct is back: its n says how many */
+{
+    if (GM_QAC(sh.gm.pk[set])) gq_copy(GQ_CUR(sh, set), GQ_SNAP(sh, depth, slot), set ? sh.dpool.n : sh.pool.n);
+}
+/* the same by all lanes of the workgroup */
+__device__ __forceinline__ void gq_save_par(Sh &sh, int set, int depth, int slot)
+{
+    if (!GM_QAC(sh.gm.pk[set])) return;
+    const int n = set ? sh.dpool.n : sh.pool.n;
+    int16_t *d = GQ_SNAP(sh, depth, slot);
+    const int16_t *c = GQ_CUR(sh, set);
+    for (int i = threadIdx.x; i < n; i += B) d[i] = c[i];
+}
+
+/* would the pool take another state?  (the constant and the uniform pool take everything) */
+__device__ __forceinline__ bool gm_accepts(const Pool &m, int kind)
+{
+    return kind == FC_PK_CONSTANT || kind == FC_PK_UNIFORM || m.n < m.max_domains;
+}
+/* ->append; true: the pool's list grew */
+__device__ bool gm_take(Sh &sh, Pool &m, int kind, int set, int state)
+{
+    if (kind == FC_PK_CONSTANT) return false;
+    if (kind != FC_PK_UNIFORM && m.n >= m.max_domains) return false;
+    if (GM_QAC(kind)) { int16_t *q = GQ_CUR(sh, set); q[m.n] = m.n > 0 ? q[m.n - 1] : (int16_t) 0; }
+    if (GM_RLE(kind) && state == 0) { m.d0_index = 0; m.d0_n = 1; }
+    m.n++;
+    return true;
+}
+/* a non-auxiliary state is offered to both pools (both of normal_domains / delta_domains are on) */
+__device__ void gm_offer(DevFrame &F, Sh &sh, int s)
+{
+    const int L = sh.pool.n > sh.dpool.n ? sh.pool.n : sh.dpool.n;        /* length of the common list */
+    bool grow = gm_take(sh, sh.pool, sh.gm.pk[0], 0, s);
+    if (F.pred_on) grow = gm_take(sh, sh.dpool, sh.gm.pk[1], 1, s) || grow;
+    F.pos[s] = -1;
+    if (grow) { F.pos[s] = (short) L; F.pool_states[L] = (short) s; }
+}
+#endif
+
 /* the same snapshots taken by the whole workgroup around a linear-combination search
  * (codec/subdivide.c:188-237): before it, models -> slot 0 (+ tree model); after it, models ->
  * slot 1 and slot 0 -> models.  One 16-byte element per lane. */
@@ -2129,9 +2250,15 @@ __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, 
     for (int i = tid; i < sh.n16; i += B) SNAP_AT(sh, depth, 0)[i] = ((const uint4 *) &sh.cb)[i];
     if (tid >= 96 && tid < 96 + TM_N16(ML)) TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
     if (tid == 128) fr.pool0 = sh.pool;
+#if FC_GM
+    gq_save_par(sh, 0, depth, 0);
+#endif
     if (sh.nslot == 5 && !fr.delta) {
         if (tid == 129) fr.dpool0 = sh.dpool;
         for (int i = tid; i < sh.n16; i += B) SNAP_AT(sh, depth, 2)[i] = ((const uint4 *) &sh.dcb)[i];
+#if FC_GM
+        gq_save_par(sh, 1, depth, 2);
+#endif
     }
     return;
 #endif
@@ -2157,6 +2284,18 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
         SNAP_AT(sh, depth, 1)[i] = ((const uint4 *) &sh.cb)[i];
         ((uint4 *) &sh.cb)[i] = SNAP_AT(sh, depth, 0)[i];
     }
+#if FC_GM
+    if (GM_QAC(sh.gm.pk[0])) {           /* pool_lc <- the pool after the combination; the pool <- pool0 (below) */
+        const int n1 = sh.pool.n, n0 = fr.pool0.n;
+        int16_t *cur = GQ_CUR(sh, 0), *s1 = GQ_SNAP(sh, depth, 1);
+        const int16_t *s0 = GQ_SNAP(sh, depth, 0);
+        for (int i = tid; i < (n1 > n0 ? n1 : n0); i += B) {
+            if (i < n1) s1[i] = cur[i];
+            if (i < n0) cur[i] = s0[i];
+        }
+    }
+    __syncthreads();                     /* sh.pool.n was read above: it changes now */
+#endif
     if (tid == 128) {
 #else
     if (tid < sh.n16) {
@@ -2361,6 +2500,9 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
 {
     const int s = sh.states;
     F.pos[s] = -1;
+#if FC_GM
+    if (!aux) gm_offer(F, sh, s);
+#else
     if (!aux && sh.pool.n < sh.pool.max_domains) {
         F.pos[s] = (short) sh.pool.n;
         F.pool_states[sh.pool.n++] = (short) s;
@@ -2368,6 +2510,7 @@ __device__ void store_new_state(DevFrame &__restrict__ F, Sh &sh, SFrame &fr, in
         if (sh.nslot == 5) sh.dpool.n = sh.pool.n;      /* one list, two sets of counters */
 #endif
     }
+#endif
     fr.rrange.into[0] = NOEDGE;
     fr.rrange.tree = s;
     for (int l = 0; l < 2; l++) {
@@ -2735,8 +2878,16 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 fr.pool0 = sh.pool;
                 snap_save(F, sh, sp, 0);
                 tm_save(sh, sp, ML);
+#if FC_GM
+                gq_save(sh, 0, sp, 0);
+#endif
 #if FC_VARIANT_BIG
-                if (sh.nslot == 5 && !fr.delta) { fr.dpool0 = sh.dpool; snap_save_d(sh, sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) {
+                    fr.dpool0 = sh.dpool; snap_save_d(sh, sp, 2);
+#if FC_GM
+                    gq_save(sh, 1, sp, 2);
+#endif
+                }
 #endif
             }
             fr.states = sh.states;
@@ -2788,8 +2939,14 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #if FC_VARIANT_BIG
                 fr.pool_lc = sh.pool;
                 snap_save(F, sh, sp, 1);
+#if FC_GM
+                gq_save(sh, 0, sp, 1);
+#endif
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sp, 0);
+#if FC_GM
+                gq_load(sh, 0, sp, 0);
+#endif
 #else
                 /* a node above the largest block level: no linear combination has touched the
                  * models since the snapshot of its entry */
@@ -2954,8 +3111,16 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 sh.pool = fr.pool0;
                 snap_load(F, sh, sp, 0);
                 tm_load(sh, sp, ML);
+#if FC_GM
+                gq_load(sh, 0, sp, 0);
+#endif
 #if FC_VARIANT_BIG
-                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) {
+                    sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2);
+#if FC_GM
+                    gq_load(sh, 1, sp, 2);
+#endif
+                }
 #endif
                 sh.states = fr.states;
                 if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
@@ -2968,9 +3133,17 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 sh.pool = fr.pool_lc;
                 snap_load(F, sh, sp, 1);
                 tm_load(sh, sp, ML);
+#if FC_GM
+                gq_load(sh, 0, sp, 1);
+#endif
 #if FC_VARIANT_BIG
                 /* the linear combination left the resting models as they were at the entry */
-                if (sh.nslot == 5 && !fr.delta) { sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2); }
+                if (sh.nslot == 5 && !fr.delta) {
+                    sh.dpool = fr.dpool0; snap_load_d(sh, sp, 2);
+#if FC_GM
+                    gq_load(sh, 1, sp, 2);
+#endif
+                }
 #endif
                 rg = fr.lrange;
                 sh.states = fr.states;
@@ -2983,7 +3156,13 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
 #if FC_VARIANT_BIG
                 /* with a second rle pool as delta pool a state that neither pool takes keeps no
                  * tables (codec/subdivide.c:571-583,607; the constant pool takes every state) */
+#if FC_GM
+                /* ... in general: a state that neither pool takes (without prediction the delta pool is the
+                 * constant pool, which takes everything) */
+                if (!(gm_accepts(sh.pool, sh.gm.pk[0]) || !F.pred_on || gm_accepts(sh.dpool, sh.gm.pk[1]))) aux = 1;
+#else
                 if (F.pred_on && sh.pool.n >= sh.pool.max_domains) aux = 1;
+#endif
 #endif
 #if FC_SPEC
                 /* (volatile: see spec_mode) */
@@ -3027,9 +3206,15 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             /* what the recursion left behind */
             fr.pool_rec = sh.pool; fr.dpool_rec = sh.dpool;
             snap_save(F, sh, sp, 3); snap_save_d(sh, sp, 4); tm_save(sh, sp, ML, 1);
+#if FC_GM
+            gq_save(sh, 0, sp, 3); gq_save(sh, 1, sp, 4);
+#endif
             /* back to the models of the entry */
             sh.pool = fr.pool0; sh.dpool = fr.dpool0;
             snap_load(F, sh, sp, 0); snap_load_d(sh, sp, 2); tm_load(sh, sp, ML, 0);
+#if FC_GM
+            gq_load(sh, 0, sp, 0); gq_load(sh, 1, sp, 2);
+#endif
             sh.states = fr.states;
             if (sh.flim > sh.states) sh.flim = sh.states & ~(GRAM_FB - 1);
             if (fr.try_pred == 2) {          /* mc_prediction, prediction.c:262-289 */
@@ -3047,6 +3232,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 fr.nd_w = btor_fast(sym, sh.par.dc_mant, sh.par.dc_range);
                 fr.nd_tbits = tree_bits_dev(sh, ML, 0, rg.level, 1);
                 fr.nd_wbits = (float) (0.0 - log2((double) (cnt / (float) sh.cb.tot[0])));
+#if FC_GM
+                if (sh.gm.ck[0] == FC_CK_UNIFORM) fr.nd_wbits = (float) (sh.par.dc_mant + 1);     /* uniform_bits, codec/coeff.c:155-170 */
+#endif
             }
             fr.pred_costs = fr.price * (fr.nd_wbits + fr.nd_tbits);
             phase = PH_PRED_GO;
@@ -3074,6 +3262,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             /* no residual search: everything back as the recursion left it */
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
             snap_load(F, sh, sp, 3); snap_load_d(sh, sp, 4); tm_load(sh, sp, ML, 1);
+#if FC_GM
+            gq_load(sh, 0, sp, 3); gq_load(sh, 1, sp, 4);
+#endif
             sh.states = fr.rec_states;
             fr.rg.prediction = 0;
             phase = PH_DECIDE;
@@ -3126,6 +3317,9 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
             }
             sh.pool = fr.pool_rec; sh.dpool = fr.dpool_rec;
             snap_load(F, sh, sp, 3); snap_load_d(sh, sp, 4); tm_load(sh, sp, ML, 1);
+#if FC_GM
+            gq_load(sh, 0, sp, 3); gq_load(sh, 1, sp, 4);
+#endif
             sh.states = fr.rec_states;
             {   /* columns of ids the residual search used are stale in older rows */
                 const int lim = fr.states & ~(GRAM_FB - 1);
@@ -3576,6 +3770,30 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #if FC_BLKEST
         sh.cum[0] = 0;
 #endif
+#if FC_GM
+        /* alloc_domain_pool and the allocators behind it (codec/domain-pool.c:203-236) for the kinds of both sets */
+        sh.gm.pk[0] = F.gm_pool[0]; sh.gm.pk[1] = F.pred_on ? F.gm_pool[1] : FC_PK_CONSTANT;
+        sh.gm.ck[0] = F.gm_coeff[0]; sh.gm.ck[1] = F.gm_coeff[1];
+        sh.gm.qa = 0; sh.gm.gq = F.gq; sh.gm.P = F.P;
+        sh.gm.base = sh.gm.kept = 0.0f; sh.gm.lg1 = 0.0;
+        sh.dpool = m;
+        for (int set = 0; set < 2; set++) {
+            Pool &pm = set ? sh.dpool : sh.pool;
+            const int k = sh.gm.pk[set];
+            int maxd = F.pool_max ? F.pool_max : 1;                 /* "Using at least DC component.", :221-226 */
+            if (k == FC_PK_BASIS) maxd = F.basis_states;
+            if (k == FC_PK_UNIFORM || k == FC_PK_CONSTANT) maxd = 0xffff;
+            pm.max_domains = (unsigned short) maxd;
+            if (!GM_RLE(k)) { pm.total = 0; for (int i = 0; i <= MAXED; i++) pm.count[i] = 0; }
+        }
+        for (int s = 0; s < F.basis_states; s++) {
+            F.pos[s] = -1;
+            if (F.domain_type[s] & 2) gm_offer(F, sh, s);
+        }
+        if ((F.domain_type[0] & 2) && F.pos[0] < 0) { F.pos[0] = 0; F.pool_states[0] = 0; }   /* no pool keeps a list */
+        if (sh.gm.pk[0] == FC_PK_CONSTANT) sh.pool.n = 1;          /* the list {0} */
+        if (sh.gm.pk[1] == FC_PK_CONSTANT) sh.dpool.n = 0;
+#else
         for (int s = 0; s < F.basis_states; s++) {
             F.pos[s] = -1;
             if ((F.domain_type[s] & 2) && m.n < m.max_domains) {
@@ -3584,6 +3802,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
                 if (s == 0) m.d0_n = 1;
             }
         }
+#endif
         /* aac model, all-ones (coeff.c:297-310) */
         sh.n16 = (32 + 2 * F.coeff_size + 15) / 16;
 #if FC_VARIANT_BIG
@@ -3635,7 +3854,9 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         for (int i = 0; i < F.d_coeff_size; i++) sh.dcb.cnt[i] = 1;
         sh.dcb.tot[0] = (short) F.d_dcs;
         for (int i = 1; i < F.coeff_nt; i++) sh.dcb.tot[i] = (short) F.d_sy;
+#if !FC_GM
         sh.dpool = sh.pool;
+#endif
         sh.dq.rpf_mant = F.d_rpf_mant; sh.dq.dc_mant = F.d_dc_mant; sh.dq.sy = F.d_sy; sh.dq.dcs = F.d_dcs;
         sh.dq.rpf_range = F.d_rpf_range; sh.dq.dc_range = F.d_dc_range;
         if (F.pred_on && F.d_coeff_size > FC_MAXCOEFF_BIG) sh.failed = FC_ERR_INTERNAL;

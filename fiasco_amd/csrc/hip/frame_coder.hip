@@ -246,6 +246,9 @@ struct __attribute__((aligned(16))) SFrame {
     float max_costs, lincomb, subdiv, ret, price;
     int   label, states, phase, leaf, coop;
     int   y_state, ny[2];        /* co-located luminance state of the range / of its children */
+#if FC_GM
+    int   rn0;                   /* Pool.n of the RESTING pool at the entry of the node (see PH_AFTER_INIT) */
+#endif
 #if FC_SPEC
     int   ckpt;                  /* a checkpoint of the workgroup was taken at the entry of this node */
 #endif
@@ -2251,6 +2254,10 @@ __device__ __forceinline__ void snap_coop_before(Sh &sh, SFrame &fr, int depth, 
     if (tid >= 96 && tid < 96 + TM_N16(ML)) TM_AT(sh, depth, 0, ML)[tid - 96] = ((const uint4 *) sh.tm)[tid - 96];
     if (tid == 128) fr.pool0 = sh.pool;
 #if FC_GM
+    /* The reference duplicates all four models at every node (codec/subdivide.c:185-192).  Inside a residual search
+     * the resting (normal) models are not touched -- except that the normal pool is offered the states the search
+     * appends (gm_offer): its length goes back with the active pool's */
+    if (tid == 130) fr.rn0 = sh.dpool.n;
     gq_save_par(sh, 0, depth, 0);
 #endif
     if (sh.nslot == 5 && !fr.delta) {
@@ -2305,6 +2312,9 @@ __device__ __forceinline__ void snap_coop_after(Sh &sh, SFrame &fr, int depth)
 #endif
         fr.pool_lc = sh.pool;
         sh.pool = fr.pool0;
+#if FC_GM
+        if (fr.delta) sh.dpool.n = (unsigned short) fr.rn0;
+#endif
     }
 }
 
@@ -2879,6 +2889,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 snap_save(F, sh, sp, 0);
                 tm_save(sh, sp, ML);
 #if FC_GM
+                fr.rn0 = sh.dpool.n;
                 gq_save(sh, 0, sp, 0);
 #endif
 #if FC_VARIANT_BIG
@@ -2946,6 +2957,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 snap_load(F, sh, sp, 0);
 #if FC_GM
                 gq_load(sh, 0, sp, 0);
+                if (fr.delta) sh.dpool.n = (unsigned short) fr.rn0;
 #endif
 #else
                 /* a node above the largest block level: no linear combination has touched the
@@ -3113,6 +3125,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 tm_load(sh, sp, ML);
 #if FC_GM
                 gq_load(sh, 0, sp, 0);
+                if (fr.delta) sh.dpool.n = (unsigned short) fr.rn0;
 #endif
 #if FC_VARIANT_BIG
                 if (sh.nslot == 5 && !fr.delta) {
@@ -3135,6 +3148,7 @@ __device__ __forceinline__ int serial_step(DevFrame &__restrict__ F, Sh &__restr
                 tm_load(sh, sp, ML);
 #if FC_GM
                 gq_load(sh, 0, sp, 1);
+                if (fr.delta) sh.dpool.n = (unsigned short) fr.rn0;
 #endif
 #if FC_VARIANT_BIG
                 /* the linear combination left the resting models as they were at the entry */

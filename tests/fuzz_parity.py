@@ -77,14 +77,22 @@ def random_options(rng, lib=None):
     basis = str(rng.choice(names))
     if os.environ.get("FUZZ_SPEC") == "1":
         basis = ""
-    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis)
+    # the other entries of the reference's model registries (fiasco_amd_c_options_set_models; the FC_GM kernel build)
+    models = None
+    if os.environ.get("FUZZ_SPEC") != "1" and rng.integers(0, 3) == 0:
+        pools = ["adaptive", "basis", "uniform", "rle", "rle-no-chroma"]
+        models = (str(rng.choice(pools)), str(rng.choice(pools)), str(rng.choice(["adaptive", "uniform"])),
+                  str(rng.choice(["adaptive", "uniform"])))
+    spec = (lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis, models)
     return spec
 
 
 def apply(o, spec):
-    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis = spec
+    lo, hi, el, dic, lvl, mant, rr, dmant, dr, cq, cd, pred, basis, models = spec
     if basis:
         o.set_basisfile(basis.encode())
+    if models:
+        assert o.lib.L.fiasco_amd_c_options_set_models(o.handle, *[m.encode() for m in models])
     o.set_prediction(*pred)
     o.set_optimizations(lo, hi, el, dic, lvl)
     o.set_quantization(mant, rr, dmant, dr)

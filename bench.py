@@ -428,7 +428,7 @@ def main():
                          "--width 3840 --height 2160 --frames-per-gpu 64 on 1/2/4/8 GPUs)")
     ap.add_argument("--k4-frames", type=int, default=256,
                     help="frames of the extra 3840x2160 pass (BASELINE config 4 on one GPU; 0 = skip)")
-    ap.add_argument("--config3-frames", type=int, default=256,
+    ap.add_argument("--config3-frames", type=int, default=1024,
                     help="frames of the extra 1920x1080 COLOUR pass (BASELINE config 3 as a batch; 0 = skip)")
     ap.add_argument("--no-k4-small", action="store_true", help="skip the 64- and 8-frame 4K launches (BASELINE config 4 as written)")
     ap.add_argument("--config5-frames", type=int, default=300,

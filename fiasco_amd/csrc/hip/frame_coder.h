@@ -37,7 +37,7 @@
 #define FC_SNAP16_NARROW 480    /* (19 depths + 4 block levels with children) x 20 uint4 = 460 at level 22, CLI models */
 #define FC_SNAP16_WIDE   840
 /* tree-model snapshots (words) of the default build: depths x 2 x MAXLEVEL, rounded to 16 bytes */
-#define FC_SNAPTM_NARROW 836    /* 19 depths x 11 uint4 (MAXLEVEL 22) */
+#define FC_SNAPTM_NARROW 988    /* 19 depths x 13 uint4 (MAXLEVEL 26: a frame the stock limits accept, coded under the limits extension -- 1080p colour, BASELINE config 3 -- stays in the 256-thread build) */
 #define FC_SNAPTM_WIDE   1092   /* 21 depths x 13 uint4 */
 #define FC_MAXSAVE  512         /* states a prediction attempt can displace: 2^(12 - 4 + 1) */
 #define FC_MAXCOEFF 224         /* int16 entries of the aac model kept in LDS: default build */

@@ -34,5 +34,22 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_spec -o kt -- python3 $
 python3 $R/profiles/summarize_rocpd.py $O/trace_spec/*_results.db > $O/spec_kernel_trace_stats.txt 2>&1
 timeout 300 python3 $R/tests/gpu_spec_batch.py 3840 2160 8 0 default > $O/spec_8x4k.txt 2>&1
 rm -rf $O/trace_spec
+# round 5: PMC traffic of the 4K launch (fiasco_frame_kernel_wide_tri), separate passes
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c -d $O/pmc4k_$c -o pmc -- python3 $R/tests/gpu_perf_probe.py 3840 2160 256 32 1 > $O/pmc4k_$c.log 2>&1
+  python3 $R/profiles/summarize_rocpd.py $O/pmc4k_$c/*_results.db > $O/pmc4k_$c.txt 2>&1
+  rm -rf $O/pmc4k_$c
+done
+# ... and kernel trace + PMC traffic of BASELINE config 5 (fiasco_frame_kernel_big_wide: 11 launches)
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_c5 -o kt -- python3 $R/tests/gpu_config5.py 300 > $O/config5.txt 2> $O/trace_c5.err
+python3 $R/profiles/summarize_rocpd.py $O/trace_c5/*_results.db > $O/config5_kernel_trace.txt 2>&1
+rm -rf $O/trace_c5
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c -d $O/pmcc5_$c -o pmc -- python3 $R/tests/gpu_config5.py 300 > $O/pmcc5_$c.log 2>&1
+  python3 $R/profiles/summarize_rocpd.py $O/pmcc5_$c/*_results.db > $O/pmcc5_$c.txt 2>&1
+  rm -rf $O/pmcc5_$c
+done
+# unit utilisation of the final kernel
+bash $R/tests/gpu_pmc_units.sh fiasco_amd/libfiasco_amd.so > $O/pmc_units.log 2>&1
 rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc $O/pmc_sq   # keep the summaries only
 grep -h fiasco $O/kernel_trace_stats.txt $O/pmc_*.txt | head -40

@@ -910,6 +910,8 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.P = fs.P; F.PA = fs.PA;
     F.gram_ls = fs.tri ? (unsigned) ((size_t) fs.P * (fs.P + 1) / 2 + fs.P) : (unsigned) fs.P * (unsigned) fs.P;
     F.color = job->image->color ? 1 : 0;
+    /* pools whose chroma list is not cut down (uniform, rle-no-chroma ...: FC_GM build) search every state: full tables */
+    F.chroma_sparse = !fa_knob("FIASCO_AMD_CHROMA_FULL") && (cp->pool_kind == FA_POOL_RLE || cp->pool_kind == FA_POOL_ADAPTIVE || cp->pool_kind == FA_POOL_BASIS);
     F.chroma_max = (int) cp->chroma_max_states;
     F.chroma_decrease = cp->chroma_decrease;
     F.plane = (unsigned long long) job->image->width * job->image->height;

@@ -95,6 +95,7 @@
 #endif
 #define FC_PIXELS    4096        /* 2^lc_max, lc_max <= 12 */
 #define FC_NIP       4           /* orthogonal vectors kept per candidate: max_elements - 1 */
+#define FC_CLMAX     2048
 #define FC_WG_PER_CU (FC_VARIANT_WIDE ? 1 : 2)
 #else
 #if FC_VARIANT_WIDE
@@ -124,6 +125,7 @@
 #endif
 #define FC_PIXELS    1024
 #define FC_NIP       2
+#define FC_CLMAX     768         /* Sh::cl: states of a chroma block with table entries somebody reads */
 #ifndef FC_WG_PER_CU
 /* workgroups (frames) per CU the kernel is built for: four 256-thread frames = 4 waves per SIMD,
  * i.e. at most 128 VGPRs and 40 KB of LDS per frame */
@@ -413,6 +415,11 @@ struct Sh {
      * level, root states of the finished bands, states that own tables (= end of Y band) */
     int      band, lc_min, tree_band[3], ystates, after_chroma;
     short    dl[64];               /* candidate list of a chroma call: pool + luminance state */
+#if !FC_SPEC
+    /* chroma bands: the states whose <sub-block, state> entries of the current block anybody reads (chroma_need) */
+    short    cl[FC_CLMAX];
+    int      cln;
+#endif
     unsigned long long red[B / 64];
     /* term lists of the state being appended (uniform for the whole workgroup) */
     int      gs_idx[2][MAXED + 1], gs_n[2], gs_c[2], gs_raw_idx[2][MAXED + 1];
@@ -1192,6 +1199,159 @@ __device__ void coop_helper(DevFrame &__restrict__ F, Sh &__restrict__ sh, unsig
 }
 #endif
 
+#if !FC_SPEC
+/* ------------------------------------------------------------------ chroma bands: tables for the states that matter
+ *
+ * init_range builds the <sub-block, state> entries of a block for EVERY state with tables (codec/subdivide.c:612-644,
+ * codec/ip.c:72-154).  In a chroma band nobody appends a state with tables (chroma states are auxiliary,
+ * codec/subdivide.c:433-436) and nothing is predicted: the entries are read by the matching pursuit of the block's
+ * ranges alone -- for the <= chroma_max states of the chroma list plus the co-located luminance state of the range
+ * (rle_generate, codec/domain-pool.c:707-735) -- and, building those, for the states they refer to one level
+ * down, and so on for (lc_max - images_level) levels.  That closure is 60 .. 150 of the 1200 .. 2700 luminance states
+ * of a 720p / 1080p frame (measured with the oracle), the same values as the full tables hold for them, and the
+ * tables of a chroma block were 60 % of a colour frame.
+ *
+ * F.hits[s] (free once the chroma list is chosen): low half = levels at which the entries of s are needed for the
+ * chroma list's sake (static, op_chroma_pool), high half = the same for the block at hand (+ the luminance states
+ * of the block's subtree).  Bit k <-> level images_level + k; bit 0 = the level-images_level dots (d5, d4). */
+__device__ __forceinline__ int hits_ld(const DevFrame &F, int s) { return __hip_atomic_load(&F.hits[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* one step of the closure on half `sft` (0 / 16): what needs level k of s needs level k - 1 of the tree children
+ * and edge targets of s */
+__device__ void chroma_need_step(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int sft)
+{
+    const int n = sh.ystates;
+    for (int s = threadIdx.x; s < n; s += B) {
+        const int m = ((hits_ld(F, s) >> sft) & 0xffff) >> 1;
+        if (!m) continue;
+        for (int l = 0; l < 2; l++) {
+            int d = TREE(F, s, l);
+            if (d != RANGE_) __hip_atomic_fetch_or(&F.hits[d], m << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; (d = INTO(F, s, l, e)) != NOEDGE; e++)
+                __hip_atomic_fetch_or(&F.hits[d], m << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+}
+
+/* end of op_chroma_pool: the part of the closure that is the same for every block (the chroma list) */
+__device__ void chroma_need_static(const DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    const int tid = threadIdx.x, n = sh.ystates, NB = F.lc_max - F.images_level;
+    __syncthreads();
+    for (int s = tid; s < n; s += B) __hip_atomic_store(&F.hits[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int i = tid; i < (int) sh.pool.n; i += B)
+        __hip_atomic_store(&F.hits[F.pool_states[i]], (1 << (NB + 1)) - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int it = 0; it < NB; it++) chroma_need_step(F, sh, 0);
+}
+
+/* per block: + the luminance states of the block's subtree (the co-located states of its ranges), compacted into sh.cl.
+ * false: more states than sh.cl holds -- the caller builds the full tables */
+__device__ bool chroma_need_block(const DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    const int tid = threadIdx.x, n = sh.ystates, il = F.images_level, NB = F.lc_max - il;
+    const int y = sh.st[sh.sp].y_state;
+    for (int s = tid; s < n; s += B) {
+        const int v = hits_ld(F, s) & 0xffff;
+        __hip_atomic_store(&F.hits[s], v | (v << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) sh.cln = 0;
+    __syncthreads();
+    if (y != RANGE_) {
+        const int nheap = (2 << (F.lc_max - sh.lc_min)) - 1;          /* nodes of the block's subtree, heap order */
+        for (int h = tid; h < nheap; h += B) {
+            const int depth = 31 - __clz(h + 1);
+            int node = y;
+            for (int b = depth - 1; b >= 0 && node != RANGE_; b--) node = TREE(F, node, ((h + 1) >> b) & 1);
+            if (node == RANGE_) continue;
+            const int lv = F.lc_max - depth, k = lv > il ? lv - il : 0;
+            __hip_atomic_fetch_or(&F.hits[node], 1 << (16 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int it = 0; it < NB; it++) chroma_need_step(F, sh, 16);
+    }
+    for (int s = tid; s < n; s += B)
+        if ((hits_ld(F, s) >> 16) && F.domain_type[s]) {
+            const int i = atomicAdd(&sh.cln, 1);
+            if (i < FC_CLMAX) sh.cl[i] = (short) s;
+        }
+    __syncthreads();
+    return sh.cln <= FC_CLMAX;
+}
+
+/* op_d5 for the states of sh.cl that need their level-images_level dots: (state, group of eight addresses) items */
+__device__ void op_d5_sparse(const DevFrame &__restrict__ F, Sh &__restrict__ sh)
+{
+    const int tid = threadIdx.x, P = F.P, NA = F.NA, ngrp = (NA + 7) / 8;
+    float *const D5 = ACT_D5(F, sh);
+    for (int it = tid; it < sh.cln * ngrp; it += B) {
+        const int s = sh.cl[it / ngrp], a0 = (it % ngrp) * 8;
+        if (!((hits_ld(F, s) >> 16) & 1)) continue;
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = F.imgT[(size_t) k * P + s];
+        for (int a = a0; a < a0 + 8 && a < NA; a++) {
+            float ip = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) ip += sh.pixels[a * 32 + k] * v[k];      /* codec/ip.c:268-295, sequential */
+            D5[D5_AT(P, NA, a, s)] = ip;
+        }
+    }
+#if FC_VARIANT_BIG
+    if (F.gl0 < F.images_level) {
+        float *const D4 = ACT_D4(F, sh);
+        for (int i = tid; i < sh.cln; i += B) {
+            const int s = sh.cl[i];
+            if (!((hits_ld(F, s) >> 16) & 1)) continue;
+            float v4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v4[k] = F.imgT4[(size_t) k * P + s];
+            for (int a = 0; a < 2 * NA; a++) {
+                float ip = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) ip += sh.pixels[a * 16 + k] * v4[k];
+                D4[(size_t) a * P + s] = ip;
+            }
+        }
+    }
+#endif
+}
+
+/* op_ipis for the (state, level) pairs of the closure: per level the items (state, slot); the additions of an entry
+ * in the reference's order -- label 0 {tree child, edges}, label 1 {...} onto zero (codec/ip.c:104-146) */
+__device__ void op_ipis_sparse(const DevFrame &__restrict__ F, Sh &__restrict__ sh, int level)
+{
+    const int tid = threadIdx.x, il = F.images_level, P = F.P;
+    float *const ipis = ACT_IPIS(F, sh);
+    const float *const d5 = ACT_D5(F, sh);
+    for (int lv = il + 1; lv <= level; lv++) {
+        const int delta = level - lv, cnt = 1 << delta, slot0 = cnt - 1, k = lv - il;
+        const bool first = lv == il + 1;
+        for (int it = tid; it < sh.cln * cnt; it += B) {
+            const int s = sh.cl[it >> delta], j = it & (cnt - 1);
+            if (!((hits_ld(F, s) >> (16 + k)) & 1)) continue;
+            float acc = 0;
+            for (int l = 0; l < 2; l++) {
+                int d = TREE(F, s, l);
+                /* the entry of state d one level down: sub-block 2 j + l of the level below */
+#if FC_D5T
+#define SRC(d) (first ? d5[D5_AT(P, F.NA, j * 2 + l, (d))] : ipis[(size_t) ((slot0 * 2 + 1) + j * 2 + l) * P + (d)])
+#else
+#define SRC(d) (first ? d5[(size_t) (j * 2 + l) * P + (d)] : ipis[(size_t) ((slot0 * 2 + 1) + j * 2 + l) * P + (d)])
+#endif
+                if (d != RANGE_) acc += SRC(d);
+                for (int e = 0; (d = INTO(F, s, l, e)) != NOEDGE; e++) acc += WEIGHT(F, s, l, e) * SRC(d);
+#undef SRC
+            }
+            ipis[(size_t) (slot0 + j) * P + s] = acc;
+        }
+        __syncthreads();
+    }
+}
+#endif
+
 /* codec/subdivide.c:504-541,612-644 */
 /* from: the entries of the states below it are in the tables already (FC_SPEC: a table worker has
  * computed them ahead of the chain); otherwise 0 */
@@ -1231,9 +1391,15 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
         }
     }
     __syncthreads();
+#if !FC_SPEC
+    /* chroma bands: entries for the states somebody reads only (chroma_need_block) */
+    const bool sparse = sh.band && !F.bx && F.chroma_sparse && chroma_need_block(F, sh);
+#else
+    const bool sparse = false;
+#endif
 #if FC_VARIANT_BIG
     /* the helpers start on the block while this workgroup sums the norms (LDS only) */
-    const int coopD = coop_publish(F, sh, level, from);
+    const int coopD = sparse ? 0 : coop_publish(F, sh, level, from);
 #endif
     /* squared norms of every sub-block, sequential as codec/approx.c:388-389 */
     for (int slot = tid; slot < F.NS; slot += B) {
@@ -1252,6 +1418,18 @@ __device__ __noinline__ void op_init_range(DevFrame &__restrict__ F, Sh &__restr
     }
 #ifdef FC_SERIAL_PROFILE
     unsigned long long tp0 = wall_clock64();
+#endif
+#if !FC_SPEC
+    if (sparse) {
+        op_d5_sparse(F, sh);
+        __syncthreads();
+        op_ipis_sparse(F, sh, level);
+        if (tid == 0) {          /* what was built, not what the reference builds: cln states */
+            sh.cnt.bytes_img += (unsigned long long) sh.cln * (4ull * 32 + 4ull * F.NS) + 4ull * npx;
+            sh.cnt.n_blocks++;
+        }
+        return;
+    }
 #endif
 #if FC_VARIANT_BIG
     if (coopD) {
@@ -1696,6 +1874,9 @@ __device__ __noinline__ void op_chroma_pool(DevFrame &__restrict__ F, Sh &__rest
     __syncthreads();
     if (longl) { for (int i = tid; i < (int) m.n; i += B) F.pos[F.pool_states[i]] = (short) i; }
     else if (tid < (int) m.n) F.pos[sh.dl[tid]] = (short) tid;
+#if !FC_SPEC
+    if (!F.bx && F.chroma_sparse) chroma_need_static(F, sh);
+#endif
 }
 
 #if FC_VARIANT_BIG

@@ -115,8 +115,9 @@ def pmc_traffic(frames, w, h):
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
-        if (frames, w, h) == (j.get("frames_per_launch", 768), j.get("width", 1920), j.get("height", 1080)):
-            return j["fetch_bytes_per_launch"] + j["write_bytes_per_launch"]
+        for e in (j if isinstance(j, list) else [j]):
+            if (frames, w, h) == (e.get("frames_per_launch", 768), e.get("width", 1920), e.get("height", 1080)):
+                return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
     return None
 
 
@@ -215,7 +216,7 @@ def k4_pass(lib, nframes, rank):
             "kernel_only_frames_per_s": st.frames / ks if ks else None, "launches": int(st.launches),
             "reencoded_frames": int(st.reencodes), "frames_by_kernel_build": list(st.frames_by_build),
             "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9 if ks else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": None,
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": pmc_traffic(nframes, w, h),
                          "kernel": "fiasco_frame_kernel_wide_tri", "avg_launch_ms": st.kernel_ms / max(st.launches, 1),
                          "algorithmic_bytes_per_launch": alg / max(st.launches, 1)},
             "parity": ("stream md5 of survey frame == patched reference (%s)" % md5[:12])

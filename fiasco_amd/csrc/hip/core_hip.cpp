@@ -2520,4 +2520,107 @@ extern "C" int fa_core_encode_frames(unsigned n, fa_job *jobs)
     return good;
 }
 
+/* ------------------------------------------------------------------ gather of the streams over RCCL
+ *
+ * One process per GPU (BASELINE config 4): every rank encodes its share of the frames -- frame i of the
+ * job on rank i mod W -- and the finished byte strings (kilobytes per frame) meet on one rank: two small all-gathers for
+ * the counts and lengths, one padded all-gather for the payloads, over xGMI.  No data-path collective exists; this is
+ * the only communication of the job.  RCCL is NOT a link-time dependency of the library: the entry points are taken
+ * from the copy the process already has (the one that made the caller's communicator), else from librccl.so. */
+#include <dlfcn.h>
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, void *);
+typedef const char *(*nccl_errstr_fn)(int);
+enum { FA_NCCL_UINT8 = 1, FA_NCCL_UINT64 = 5 };          /* ncclDataType_t, rccl.h */
+
+extern "C" int fiasco_amd_rccl_gather(void *comm, void *stream_, int rank, int world, int root,
+                                      unsigned n_local, const unsigned char *const *data, const size_t *len,
+                                      unsigned char ***all, size_t **all_len, unsigned *n_all)
+{
+    hipStream_t stream = (hipStream_t) stream_;
+    if (all) *all = nullptr;
+    if (all_len) *all_len = nullptr;
+    if (n_all) *n_all = 0;
+    if (!comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || (n_local && (!data || !len))) {
+        fa_set_error("fiasco_amd_rccl_gather: bad arguments");
+        return 0;
+    }
+    static nccl_allgather_fn allgather = nullptr;
+    static nccl_errstr_fn errstr = nullptr;
+    if (!allgather) {
+        allgather = (nccl_allgather_fn) dlsym(RTLD_DEFAULT, "ncclAllGather");
+        errstr = (nccl_errstr_fn) dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+        if (!allgather) {
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (h) { allgather = (nccl_allgather_fn) dlsym(h, "ncclAllGather"); errstr = (nccl_errstr_fn) dlsym(h, "ncclGetErrorString"); }
+        }
+        if (!allgather) { fa_set_error("fiasco_amd_rccl_gather: no RCCL in this process (librccl.so)"); return 0; }
+    }
+    unsigned long long *d_u64 = nullptr;
+    unsigned char *d_pay = nullptr;
+    int ok = 1, rc = 0;
+    std::vector<unsigned long long> h_cnt((size_t) world * 2);
+#define GCHECK(call, what) do { if (ok && (call) != hipSuccess) { fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, hipGetErrorString(hipGetLastError())); ok = 0; } } while (0)
+#define NCHECK(call, what) do { if (ok && (rc = (call)) != 0) { fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, errstr ? errstr(rc) : "RCCL error"); ok = 0; } } while (0)
+    /* 1. counts and total bytes of every rank */
+    unsigned long long mine[2] = { n_local, 0 };
+    for (unsigned i = 0; i < n_local; i++) mine[1] += len[i];
+    GCHECK(hipMalloc((void **) &d_u64, sizeof(unsigned long long) * 2 * ((size_t) world + 1)), "hipMalloc");
+    GCHECK(hipMemcpyAsync(d_u64 + 2 * (size_t) world, mine, sizeof mine, hipMemcpyHostToDevice, stream), "upload");
+    NCHECK(allgather(d_u64 + 2 * (size_t) world, d_u64, 2, FA_NCCL_UINT64, comm, stream), "all-gather of the counts");
+    GCHECK(hipMemcpyAsync(h_cnt.data(), d_u64, sizeof(unsigned long long) * 2 * (size_t) world, hipMemcpyDeviceToHost, stream), "download");
+    GCHECK(hipStreamSynchronize(stream), "synchronize");
+    if (d_u64) (void) hipFree(d_u64);
+    d_u64 = nullptr;
+    size_t maxn = 0, maxb = 0, total = 0;
+    for (int r = 0; ok && r < world; r++) {
+        if (h_cnt[2 * r] > maxn) maxn = (size_t) h_cnt[2 * r];
+        if (h_cnt[2 * r + 1] > maxb) maxb = (size_t) h_cnt[2 * r + 1];
+        total += (size_t) h_cnt[2 * r];
+    }
+    /* 2. per rank: maxn lengths + maxb payload bytes (padded), one all-gather of bytes */
+    const size_t slot = align_up(maxn * 8 + maxb, 16);
+    std::vector<unsigned char> h_send(slot ? slot : 16, 0), h_recv(ok && rank == root ? slot * (size_t) world : 0);
+    if (ok && slot) {
+        size_t o = maxn * 8;
+        for (unsigned i = 0; i < n_local; i++) {
+            const unsigned long long l = len[i];
+            memcpy(h_send.data() + (size_t) i * 8, &l, 8);
+            memcpy(h_send.data() + o, data[i], len[i]);
+            o += len[i];
+        }
+        GCHECK(hipMalloc((void **) &d_pay, slot * ((size_t) world + 1)), "hipMalloc");
+        GCHECK(hipMemcpyAsync(d_pay + slot * (size_t) world, h_send.data(), slot, hipMemcpyHostToDevice, stream), "upload");
+        NCHECK(allgather(d_pay + slot * (size_t) world, d_pay, slot, FA_NCCL_UINT8, comm, stream), "all-gather of the streams");
+        if (rank == root) GCHECK(hipMemcpyAsync(h_recv.data(), d_pay, slot * (size_t) world, hipMemcpyDeviceToHost, stream), "download");
+        GCHECK(hipStreamSynchronize(stream), "synchronize");
+        if (d_pay) (void) hipFree(d_pay);
+    }
+#undef GCHECK
+#undef NCHECK
+    if (!ok) return 0;
+    if (rank != root || !all || !all_len || !n_all) return 1;
+    /* 3. the root: stream k of rank r is item r + k * world of the job (the round-robin deal) */
+    unsigned char **out = (unsigned char **) calloc(total ? total : 1, sizeof *out);
+    size_t *olen = (size_t *) calloc(total ? total : 1, sizeof *olen);
+    if (!out || !olen) { free(out); free(olen); fa_set_error("fiasco_amd_rccl_gather: out of memory"); return 0; }
+    for (int r = 0; r < world; r++) {
+        const unsigned char *base = h_recv.data() + slot * (size_t) r;
+        size_t o = maxn * 8;
+        for (size_t k = 0; k < (size_t) h_cnt[2 * r]; k++) {
+            unsigned long long l;
+            memcpy(&l, base + k * 8, 8);
+            const size_t item = (size_t) r + k * (size_t) world;
+            if (item < total) {
+                out[item] = (unsigned char *) malloc(l ? (size_t) l : 1);
+                if (out[item]) memcpy(out[item], base + o, (size_t) l);
+                olen[item] = (size_t) l;
+            }
+            o += (size_t) l;
+        }
+    }
+    *all = out; *all_len = olen; *n_all = (unsigned) total;
+    return 1;
+}
+
 #include "frame_decoder.inc"

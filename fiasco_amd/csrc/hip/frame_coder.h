@@ -69,8 +69,10 @@ enum { FC_CK_ADAPTIVE = 0, FC_CK_UNIFORM = 1 };
 #define FC_N16(coeffs)  ((32 + 2 * (coeffs) + 15) / 16)
 #define FC_N16MAX       FC_N16(FC_MAXCOEFF_BIG)       /* 82, FC_HM: 643 */
 #define FC_MAXBASIS 16          /* states of an initial basis that travels inside DevFrame (else DevFrame.bx) */
-#define FC_BX_BYTES (64 * 1024)  /* room for DevFrame.bx in a slab: 2700 basis states */
+#define FC_BX_BYTES (64 * 1024)  /* room for DevFrame.bx in a slab: 818 basis states (12 lists of 6+1 ints each = 80 bytes) */
+#ifndef FC_TRI_HOT
 #define FC_TRI_HOT  8           /* states whose Gram columns the triangular layout also keeps as rows (DevFrame.gcol) */
+#endif
 
 enum { FC_OK = 1, FC_ERR_STATES = 2, FC_ERR_CAPACITY = 3, FC_ERR_NOROOT = 4, FC_ERR_INTERNAL = 5,
        FC_ERR_QUEUE = 6,      /* frame queue: no free slab arrived in time, encode again with a slab of its own */

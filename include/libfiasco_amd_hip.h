@@ -8,6 +8,7 @@
  */
 #ifndef LIBFIASCO_AMD_HIP_H
 #define LIBFIASCO_AMD_HIP_H 1
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -67,6 +68,17 @@ int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int nar
  * "oracle-cpu" for the test-only oracle library (reference seam: codec/approx.h:24-27,
  * codec/ip.h:22-34, codec/subdivide.h -- the functions the backend replaces). */
 const char *fiasco_amd_core_name(void);
+
+/* One process per GPU (BASELINE config 4: frames dealt round robin to the ranks, item i on rank
+ * i mod world): the finished streams of all ranks meet on `root` -- the job's only communication, three small
+ * collectives over RCCL / xGMI (counts, then lengths + payloads in one padded all-gather).  `comm` is the caller's
+ * ncclComm_t, `stream` a hipStream_t (or NULL); every rank passes its n_local streams.  On `root`: *all / *all_len hold
+ * the *n_all streams of the job in item order (free each with fiasco_amd_free(), the two arrays with free()); the other
+ * ranks get *n_all = 0.  RCCL is taken from the process at run time (no link-time dependency).  1 ok / 0 + message.
+ * In the reference nothing corresponds: it is single threaded (codec/coder.c:490-668 is the loop that is sharded). */
+int fiasco_amd_rccl_gather(void *comm, void *stream, int rank, int world, int root,
+                           unsigned n_local, const unsigned char *const *data, const size_t *len,
+                           unsigned char ***all, size_t **all_len, unsigned *n_all);
 
 /* Devices.  Frames are independent units: every batch entry -- fiasco_amd_encode_batch(),
  * the staged batches, fiasco_coder() on an all-intra stream or a video (its groups of pictures) -- spreads

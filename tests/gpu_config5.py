@@ -20,7 +20,8 @@ def main():
     with mp.get_context("fork").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
         paths = pool.map(make, [(f, os.path.join(td, "v%03d.ppm" % f)) for f in range(n)])
     import fiasco_amd
-    lib = fiasco_amd.library(); lib.set_verbosity(0)
+    lib = fiasco_amd.Library(os.environ["FIASCO_AMD_LIB"]) if os.environ.get("FIASCO_AMD_LIB") else fiasco_amd.library()
+    lib.set_verbosity(0)
     o = lib.cli_options(); o.set_prediction(1, 6, 10)
     out = os.path.join(td, "dev.fco")
     res = {}

@@ -16,6 +16,8 @@ w, h, n = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv
 gs = [int(a) for a in sys.argv[4:]] or [0, 8]
 lib = fiasco_amd.library()
 lib.set_verbosity(0)
+if max(w, h) > 2048:
+    lib.set_limits(30000, 26)
 opt = lib.cli_options()
 frames = [synth.pgm_bytes(synth.synth(w, h, 1234 if i == 0 else 1000 + i)) for i in range(n)]
 ref = None

@@ -132,6 +132,35 @@ if [ -z "${FIASCO_SKIP_REF_MODELS:-}" ]; then
     echo "ref_build: built the model-registry variants cfiasco_ref_{adaptive,uniform,basis,nochroma,rleuni}"
 fi
 
+# ---- `cfiasco -z 3' pinned (round 6): the zero-initialised variant ----
+# With -z 3 (check_for_underflow / check_for_overflow / full_search, codec/approx.c:119-206,420) the reference reads
+# members of the automatic `mp_t mp' of approximate_range() (codec/approx.c:88) that nobody has written: a step of
+# a full_search run is kept without `mp->weight[]' being set (:439-446 read it), and the retry loops walk
+# `indices[]' of a run that found nothing.  What the stock binary writes then depends on what the stack held.  This
+# DECLARED variant defines those reads: ONE throw-away copy of codec/approx.c under /tmp with the declaration turned
+# into `mp_t mp = mp_zero_;' (all members zero), compiled with the same flags and linked with the stock objects:
+# cfiasco_ref_z3.  It pins the oracle's and the device's -z 3 streams (tests/golden/make_z3.py, "z3_cases");
+# without -z 3 it writes what the stock reference writes (checked when the goldens are made).
+if [ -z "${FIASCO_SKIP_REF_Z3:-}" ] && { [ ! -x "$OUT/cfiasco_ref_z3" ] || [ "$0" -nt "$OUT/cfiasco_ref_z3" ]; }; then
+    mkdir -p "$OUT/obj_z3"
+    TMPA=$(mktemp /tmp/fiasco_approx_XXXXXX.c)
+    sed -e 's/^   mp_t\t  mp;$/   static const mp_t mp_zero_; mp_t mp = mp_zero_;/' "$REF/codec/approx.c" > "$TMPA"
+    [ "$(grep -c 'static const mp_t mp_zero_; mp_t mp = mp_zero_;' "$TMPA")" = 1 ] \
+        || { echo "ref_build: the -z 3 zero-initialisation patch did not apply" >&2; rm -f "$TMPA"; exit 1; }
+    [ "$(diff "$REF/codec/approx.c" "$TMPA" | grep -c '^[<>]')" = 2 ] \
+        || { echo "ref_build: the -z 3 patch changed more than one line" >&2; rm -f "$TMPA"; exit 1; }
+    gcc $CFLAGS -c "$TMPA" -o "$OUT/obj_z3/codec_approx.o"
+    rm -f "$TMPA"
+    zobjs=()
+    for o in "${objs[@]}"; do
+        case "$o" in */codec_approx.o) zobjs+=("$OUT/obj_z3/codec_approx.o");; *) zobjs+=("$o");; esac
+    done
+    gcc -shared -fcommon -o "$OUT/libfiasco_ref_z3.so" "${zobjs[@]}" -lm
+    gcc -fcommon -o "$OUT/cfiasco_ref_z3" "${cli[@]}" -L"$OUT" -lfiasco_ref_z3 -Wl,-rpath,'$ORIGIN' -lm
+    echo "z3_variant: codec/approx.c:88 \`mp_t mp' zero-initialised (one sed line on a /tmp copy of that file)" >> "$OUT/BUILD_INFO"
+    echo "ref_build: built $OUT/cfiasco_ref_z3 (-z 3 with defined reads)"
+fi
+
 # ---- limits extension: patched throw-away copy, same flags ----
 if [ -z "${FIASCO_SKIP_REF_BIG:-}" ] && { [ ! -x "$OUT/cfiasco_ref_big" ] || [ "$0" -nt "$OUT/cfiasco_ref_big" ]; }; then
     TMPSRC=$(mktemp -d /tmp/fiasco_ref_big.XXXXXX)

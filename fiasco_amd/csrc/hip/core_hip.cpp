@@ -911,6 +911,7 @@ static void fill_frame(FrameSlot &fs, const fa_job *job)
     F.gram_ls = fs.tri ? (unsigned) ((size_t) fs.P * (fs.P + 1) / 2 + fs.P) : (unsigned) fs.P * (unsigned) fs.P;
     F.color = job->image->color ? 1 : 0;
     /* pools whose chroma list is not cut down (uniform, rle-no-chroma ...: FC_GM build) search every state: full tables */
+    F.chroma_cl_cap = fa_knob("FIASCO_AMD_CLMAX") ? atoi(fa_knob("FIASCO_AMD_CLMAX")) : 0;     /* tests: the overflow path of Sh::cl */
     F.chroma_sparse = !fa_knob("FIASCO_AMD_CHROMA_FULL") && (cp->pool_kind == FA_POOL_RLE || cp->pool_kind == FA_POOL_ADAPTIVE || cp->pool_kind == FA_POOL_BASIS);
     F.chroma_max = (int) cp->chroma_max_states;
     F.chroma_decrease = cp->chroma_decrease;
@@ -2186,8 +2187,15 @@ static int core1_finish2(void *h, int resubmit)
  *
  * Which devices: FIASCO_AMD_DEVICES="0,1,4" if set (an id may repeat -- two shares on one GPU: the test of
  * this path on a 1-GPU box); else, once fiasco_amd_set_device(d) has been called -- one process per GPU,
- * the multi-process harness -- just d; else every visible device.  With one device nothing below
- * starts a thread or touches the current device: the calls run where they always ran. */
+ * the multi-process harness -- just d; else every visible device.  With one device nothing below starts a
+ * thread; every share of a call -- also the only one -- runs bound to its device (bind_share) and the caller's
+ * current device is restored afterwards (for_each_share).
+ *
+ * Threading contract: the batch entries may be called from several host threads.  Calls with ONE share run
+ * concurrently as before (each on its calling thread).  The worker threads of the shares k >= 1 belong to the
+ * process, not to a batch: calls that spread over several shares are serialised by g_share_lock, one phase
+ * (stage / submit / finish / upload) at a time.  The workers are detached and parked on a condition variable;
+ * they are never joined (a dlclose of the library with several devices in use is not supported). */
 static std::vector<int> g_devices;              /* empty = not resolved yet */
 static int  g_device_explicit = -1;             /* fiasco_amd_set_device() */
 static std::vector<DevState *> g_dev_state;     /* [k] for share k (k >= 1; share 0 uses g_state0) */
@@ -2320,6 +2328,7 @@ struct ShareWorker {
     int state = 0;                  /* 0 idle, 1 task posted, 2 task done */
 };
 static std::vector<ShareWorker *> g_workers;       /* [k], k >= 1; [0] unused */
+static pthread_mutex_t g_share_lock = PTHREAD_MUTEX_INITIALIZER;    /* one multi-share phase at a time (see above) */
 
 static void bind_share(size_t k)
 {
@@ -2371,6 +2380,9 @@ template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
     int cur = -1;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     if (!have_cur) (void) hipGetLastError();
+    /* the workers' call / ctx / state slots are per process: two host threads driving two multi-share batches
+     * would overwrite each other's task (a lost task, or a wait for `state == 2' that never ends) */
+    if (D > 1) pthread_mutex_lock(&g_share_lock);
     auto tramp = [](void *p, size_t k) { (*(Fn *) p)(k); };
     std::vector<ShareWorker *> posted(D, nullptr);
     for (size_t k = 1; k < D; k++) {
@@ -2393,6 +2405,7 @@ template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
             pthread_mutex_unlock(&w->mu);
         } else { bind_share(k); fn(k); }             /* no thread: one after the other */
     }
+    if (D > 1) pthread_mutex_unlock(&g_share_lock);
     t_dev = &g_state0;
     if (have_cur) {
         int now = -1;
@@ -2487,7 +2500,16 @@ extern "C" int16_t *fa_core_upload_buffer(void *h, size_t bytes)
     if (bytes > M->up_host_bytes) {
         if (M->up_host) (void) hipHostFree(M->up_host);
         M->up_host = nullptr; M->up_host_bytes = 0;
-        if (hipHostMalloc((void **) &M->up_host, bytes, hipHostMallocPortable) != hipSuccess) { M->up_host = nullptr; (void) hipGetLastError(); return nullptr; }
+        if (hipHostMalloc((void **) &M->up_host, bytes, hipHostMallocPortable) != hipSuccess) {
+            M->up_host = nullptr; (void) hipGetLastError();
+            /* the shares still point into the buffer that was just freed: a later commit must not bounds-check
+             * against it or copy from it */
+            for (size_t k = 0; k < M->parts.size(); k++) {
+                Staged *S = (Staged *) M->parts[k].staged;
+                if (S && S->up_host_shared) { S->up_host = nullptr; S->up_host_bytes = 0; S->up_host_shared = false; }
+            }
+            return nullptr;
+        }
         M->up_host_bytes = bytes;
     }
     for (size_t k = 0; k < M->parts.size(); k++) {
@@ -2556,31 +2578,72 @@ extern "C" int fiasco_amd_rccl_gather(void *comm, void *stream_, int rank, int w
         }
         if (!allgather) { fa_set_error("fiasco_amd_rccl_gather: no RCCL in this process (librccl.so)"); return 0; }
     }
+    /* Failure discipline: a collective that one rank skips hangs every other rank.  So every rank takes part in
+     * every collective the OTHERS will enter: a rank-local failure travels as a flag in the next message -- word 2 of
+     * the counts, then a status round after the payload buffers have been allocated (whose size no rank knows before
+     * the counts are in) -- and all ranks, looking at the same gathered words, fail TOGETHER before the all-gather of
+     * the streams.  The one exception is the first allocation (24 (W + 1) bytes): a rank that cannot get that cannot
+     * signal anything.  The root's return value is the job's; a rank that is not the root returns 1 once its part is
+     * delivered. */
     unsigned long long *d_u64 = nullptr;
     unsigned char *d_pay = nullptr;
     int ok = 1, rc = 0;
-    std::vector<unsigned long long> h_cnt((size_t) world * 2);
-#define GCHECK(call, what) do { if (ok && (call) != hipSuccess) { fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, hipGetErrorString(hipGetLastError())); ok = 0; } } while (0)
-#define NCHECK(call, what) do { if (ok && (rc = (call)) != 0) { fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, errstr ? errstr(rc) : "RCCL error"); ok = 0; } } while (0)
-    /* 1. counts and total bytes of every rank */
-    unsigned long long mine[2] = { n_local, 0 };
+    const size_t W = (size_t) world;
+    std::vector<unsigned long long> h_cnt(W * 3), h_st(W * 3);
+#define GCHECK(call, what) do { if ((call) != hipSuccess) { if (ok) fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, hipGetErrorString(hipGetLastError())); ok = 0; } } while (0)
+#define NCHECK(call, what) do { if ((rc = (call)) != 0) { if (ok) fa_set_error("fiasco_amd_rccl_gather: %s: %s", what, errstr ? errstr(rc) : "RCCL error"); ok = 0; } } while (0)
+    /* 1. counts, total bytes and failure flag of every rank */
+    unsigned long long mine[3] = { n_local, 0, 0 };
     for (unsigned i = 0; i < n_local; i++) mine[1] += len[i];
-    GCHECK(hipMalloc((void **) &d_u64, sizeof(unsigned long long) * 2 * ((size_t) world + 1)), "hipMalloc");
-    GCHECK(hipMemcpyAsync(d_u64 + 2 * (size_t) world, mine, sizeof mine, hipMemcpyHostToDevice, stream), "upload");
-    NCHECK(allgather(d_u64 + 2 * (size_t) world, d_u64, 2, FA_NCCL_UINT64, comm, stream), "all-gather of the counts");
-    GCHECK(hipMemcpyAsync(h_cnt.data(), d_u64, sizeof(unsigned long long) * 2 * (size_t) world, hipMemcpyDeviceToHost, stream), "download");
-    GCHECK(hipStreamSynchronize(stream), "synchronize");
-    if (d_u64) (void) hipFree(d_u64);
-    d_u64 = nullptr;
-    size_t maxn = 0, maxb = 0, total = 0;
-    for (int r = 0; ok && r < world; r++) {
-        if (h_cnt[2 * r] > maxn) maxn = (size_t) h_cnt[2 * r];
-        if (h_cnt[2 * r + 1] > maxb) maxb = (size_t) h_cnt[2 * r + 1];
-        total += (size_t) h_cnt[2 * r];
+    if (hipMalloc((void **) &d_u64, sizeof(unsigned long long) * 3 * (W + 1)) != hipSuccess) {
+        fa_set_error("fiasco_amd_rccl_gather: hipMalloc: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
     }
-    /* 2. per rank: maxn lengths + maxb payload bytes (padded), one all-gather of bytes */
-    const size_t slot = align_up(maxn * 8 + maxb, 16);
-    std::vector<unsigned char> h_send(slot ? slot : 16, 0), h_recv(ok && rank == root ? slot * (size_t) world : 0);
+    GCHECK(hipMemcpyAsync(d_u64 + 3 * W, mine, sizeof mine, hipMemcpyHostToDevice, stream), "upload");
+    NCHECK(allgather(d_u64 + 3 * W, d_u64, 3, FA_NCCL_UINT64, comm, stream), "all-gather of the counts");
+    GCHECK(hipMemcpyAsync(h_cnt.data(), d_u64, sizeof(unsigned long long) * 3 * W, hipMemcpyDeviceToHost, stream), "download");
+    GCHECK(hipStreamSynchronize(stream), "synchronize");
+    size_t maxn = 0, maxb = 0, total = 0;
+    if (ok) {
+        for (size_t r = 0; r < W; r++) {
+            if (h_cnt[3 * r] > maxn) maxn = (size_t) h_cnt[3 * r];
+            if (h_cnt[3 * r + 1] > maxb) maxb = (size_t) h_cnt[3 * r + 1];
+            total += (size_t) h_cnt[3 * r];
+        }
+        /* the deal must be round robin (item i on rank i mod W): rank r holds ceil((total - r) / W) streams -- anything
+         * else (or garbage from a rank whose upload failed) would be put in the wrong places below; every rank sees the
+         * same words and fails alike */
+        for (size_t r = 0; r < W; r++) {
+            const size_t want = total > r ? (total - r + W - 1) / W : 0;
+            if ((size_t) h_cnt[3 * r] != want || h_cnt[3 * r + 2] != 0) {
+                fa_set_error(h_cnt[3 * r + 2] ? "fiasco_amd_rccl_gather: rank %d reported a failure"
+                                              : "fiasco_amd_rccl_gather: rank %d holds %llu of %llu streams: the frames were not dealt round robin",
+                             (int) r, (unsigned long long) h_cnt[3 * r], (unsigned long long) total);
+                ok = 0;
+                break;
+            }
+        }
+    }
+    /* 2. per rank: maxn lengths + maxb payload bytes (padded).  Buffers first, then a status round: nobody enters the
+     * big all-gather unless everybody can (a rank whose step 1 failed locally reports that here too) */
+    const size_t slot = ok ? align_up(maxn * 8 + maxb, 16) : 0;
+    std::vector<unsigned char> h_send, h_recv;
+    unsigned long long st[3] = { ok ? 0ull : 1ull, 0, 0 };
+    if (ok && slot) {
+        try { h_send.assign(slot, 0); if (rank == root) h_recv.resize(slot * W); } catch (...) { st[0] = 1; }
+        if (!st[0] && hipMalloc((void **) &d_pay, slot * (W + 1)) != hipSuccess) { (void) hipGetLastError(); d_pay = nullptr; st[0] = 1; }
+        if (st[0]) { fa_set_error("fiasco_amd_rccl_gather: out of memory for %zu bytes per rank", slot); ok = 0; }
+    }
+    {
+        int ok2 = 1;                                   /* the status round itself; `ok' keeps the first message */
+        if (hipMemcpyAsync(d_u64 + 3 * W, st, sizeof st, hipMemcpyHostToDevice, stream) != hipSuccess) ok2 = 0;
+        if (allgather(d_u64 + 3 * W, d_u64, 3, FA_NCCL_UINT64, comm, stream) != 0) ok2 = 0;
+        if (hipMemcpyAsync(h_st.data(), d_u64, sizeof(unsigned long long) * 3 * W, hipMemcpyDeviceToHost, stream) != hipSuccess) ok2 = 0;
+        if (hipStreamSynchronize(stream) != hipSuccess) ok2 = 0;
+        if (!ok2) { (void) hipGetLastError(); if (ok) fa_set_error("fiasco_amd_rccl_gather: the status round failed"); ok = 0; }
+        for (size_t r = 0; ok2 && r < W; r++)
+            if (h_st[3 * r]) { if (ok) fa_set_error("fiasco_amd_rccl_gather: rank %d cannot take part (see its message)", (int) r); ok = 0; break; }
+    }
     if (ok && slot) {
         size_t o = maxn * 8;
         for (unsigned i = 0; i < n_local; i++) {
@@ -2589,35 +2652,40 @@ extern "C" int fiasco_amd_rccl_gather(void *comm, void *stream_, int rank, int w
             memcpy(h_send.data() + o, data[i], len[i]);
             o += len[i];
         }
-        GCHECK(hipMalloc((void **) &d_pay, slot * ((size_t) world + 1)), "hipMalloc");
-        GCHECK(hipMemcpyAsync(d_pay + slot * (size_t) world, h_send.data(), slot, hipMemcpyHostToDevice, stream), "upload");
-        NCHECK(allgather(d_pay + slot * (size_t) world, d_pay, slot, FA_NCCL_UINT8, comm, stream), "all-gather of the streams");
-        if (rank == root) GCHECK(hipMemcpyAsync(h_recv.data(), d_pay, slot * (size_t) world, hipMemcpyDeviceToHost, stream), "download");
+        GCHECK(hipMemcpyAsync(d_pay + slot * W, h_send.data(), slot, hipMemcpyHostToDevice, stream), "upload");
+        NCHECK(allgather(d_pay + slot * W, d_pay, slot, FA_NCCL_UINT8, comm, stream), "all-gather of the streams");
+        if (rank == root) GCHECK(hipMemcpyAsync(h_recv.data(), d_pay, slot * W, hipMemcpyDeviceToHost, stream), "download");
         GCHECK(hipStreamSynchronize(stream), "synchronize");
-        if (d_pay) (void) hipFree(d_pay);
     }
+    if (d_pay) (void) hipFree(d_pay);
+    if (d_u64) (void) hipFree(d_u64);
 #undef GCHECK
 #undef NCHECK
     if (!ok) return 0;
     if (rank != root || !all || !all_len || !n_all) return 1;
-    /* 3. the root: stream k of rank r is item r + k * world of the job (the round-robin deal) */
+    /* 3. the root: stream k of rank r is item r + k * world of the job (the round-robin deal, checked above) */
     unsigned char **out = (unsigned char **) calloc(total ? total : 1, sizeof *out);
     size_t *olen = (size_t *) calloc(total ? total : 1, sizeof *olen);
-    if (!out || !olen) { free(out); free(olen); fa_set_error("fiasco_amd_rccl_gather: out of memory"); return 0; }
-    for (int r = 0; r < world; r++) {
-        const unsigned char *base = h_recv.data() + slot * (size_t) r;
+    int oom = !out || !olen;
+    for (size_t r = 0; !oom && r < W; r++) {
+        const unsigned char *base = h_recv.data() + slot * r;
         size_t o = maxn * 8;
-        for (size_t k = 0; k < (size_t) h_cnt[2 * r]; k++) {
+        for (size_t k = 0; !oom && k < (size_t) h_cnt[3 * r]; k++) {
             unsigned long long l;
             memcpy(&l, base + k * 8, 8);
-            const size_t item = (size_t) r + k * (size_t) world;
-            if (item < total) {
-                out[item] = (unsigned char *) malloc(l ? (size_t) l : 1);
-                if (out[item]) memcpy(out[item], base + o, (size_t) l);
-                olen[item] = (size_t) l;
-            }
+            const size_t item = r + k * W;               /* < total: the deal was checked */
+            out[item] = (unsigned char *) malloc(l ? (size_t) l : 1);
+            if (!out[item]) { oom = 1; break; }
+            memcpy(out[item], base + o, (size_t) l);
+            olen[item] = (size_t) l;
             o += (size_t) l;
         }
+    }
+    if (oom) {
+        if (out) for (size_t i = 0; i < total; i++) free(out[i]);
+        free(out); free(olen);
+        fa_set_error("fiasco_amd_rccl_gather: out of memory");
+        return 0;
     }
     *all = out; *all_len = olen; *n_all = (unsigned) total;
     return 1;

@@ -121,6 +121,8 @@ typedef struct DevFrame {
     int      color;        /* 3 bands Y, Cb, Cr (codec/coder.c:775-800) */
     int      chroma_sparse; /* chroma bands: <sub-block, state> entries only for the states somebody reads (frame_coder.hip,
                             * chroma_need_block); 0: the full tables (FIASCO_AMD_CHROMA_FULL, tests) */
+    int      chroma_cl_cap; /* tests (FIASCO_AMD_CLMAX): a chroma block with more needed states than this takes the full tables, as
+                            * one with more than the build's FC_CLMAX (the capacity of Sh::cl) does; 0 = FC_CLMAX */
     int      chroma_max;   /* size of the chroma domain list (rle_chroma, domain-pool.c:854-879) */
     float    chroma_decrease;
     unsigned long long plane;   /* pixels per band plane in pix16 */

@@ -1260,7 +1260,11 @@ __device__ bool chroma_need_block(const DevFrame &__restrict__ F, Sh &__restrict
     if (tid == 0) sh.cln = 0;
     __syncthreads();
     if (y != RANGE_) {
-        const int nheap = (2 << (F.lc_max - sh.lc_min)) - 1;          /* nodes of the block's subtree, heap order */
+        /* nodes of the block's subtree, heap order.  The block is of level F.lc_max (op_init_range builds no other)
+         * and its ranges go down to the band's running minimum level, which the ratchet keeps at or below lc_max
+         * (band_advance); clamped all the same: a negative shift count would be undefined */
+        const int dlv = F.lc_max > sh.lc_min ? F.lc_max - sh.lc_min : 0;
+        const int nheap = (2 << dlv) - 1;
         for (int h = tid; h < nheap; h += B) {
             const int depth = 31 - __clz(h + 1);
             int node = y;
@@ -1278,7 +1282,8 @@ __device__ bool chroma_need_block(const DevFrame &__restrict__ F, Sh &__restrict
             if (i < FC_CLMAX) sh.cl[i] = (short) s;
         }
     __syncthreads();
-    return sh.cln <= FC_CLMAX;
+    const int cap = F.chroma_cl_cap > 0 && F.chroma_cl_cap < FC_CLMAX ? F.chroma_cl_cap : FC_CLMAX;
+    return sh.cln <= cap;
 }
 
 /* op_d5 for the states of sh.cl that need their level-images_level dots: (state, group of eight addresses) items */
@@ -3792,6 +3797,8 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
           unsigned long long queue_wait_ticks, unsigned coopW)
 #endif
 {
+    /* the LDS budget of the build: FC_WG_PER_CU workgroups share the 160 KB of a CU (the few words beside Sh included) */
+    static_assert(sizeof(Sh) + 256 <= (160u * 1024u) / FC_WG_PER_CU, "Sh outgrows the LDS share of a workgroup of this build");
     __shared__ Sh sh;
 #if FC_SPEC
     __shared__ Sh::SpecLocal sl_keep;

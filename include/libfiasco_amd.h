@@ -171,8 +171,9 @@ int  fiasco_amd_batch_decode_plane(const fiasco_amd_batch_t *batch, unsigned i, 
  * "adaptive", "constant", "basis", "uniform", "rle", "rle-no-chroma" and codec/coeff.c:97-131 "adaptive",
  * "uniform").  The reference has the fields and the registries but no setter; through fiasco.h a coder
  * always runs rle / rle / adaptive / adaptive.  NULL keeps a name; an unknown name is a warning and the
- * first entry of its table, as in the reference.  The HIP device coder runs the default models only and
- * refuses the others with a message (they are restated in the test oracle). */
+ * first entry of its table, as in the reference.  The HIP device coder runs every entry of both registries (the
+ * `FC_GM' build of the kernel, csrc/hip/frame_coder.h; streams pinned against builds of the reference with other
+ * registry defaults, tests/golden/MANIFEST.json "model_cases"). */
 int  fiasco_amd_c_options_set_models(fiasco_c_options_t *options, const char *domain_pool, const char *d_domain_pool,
                                      const char *rpf_model, const char *d_rpf_model);
 void fiasco_amd_batch_free(fiasco_amd_batch_t *batch);

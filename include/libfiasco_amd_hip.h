@@ -71,7 +71,11 @@ const char *fiasco_amd_core_name(void);
 
 /* One process per GPU (BASELINE config 4: frames dealt round robin to the ranks, item i on rank
  * i mod world): the finished streams of all ranks meet on `root` -- the job's only communication, three small
- * collectives over RCCL / xGMI (counts, then lengths + payloads in one padded all-gather).  `comm` is the caller's
+ * collectives over RCCL / xGMI (counts + failure flags, a status round once every rank has its buffers, then lengths +
+ * payloads in one padded all-gather).  EVERY rank must call it; a failure of one rank (a device error, no memory for
+ * the payload, a deal that is not round robin: rank r must hold ceil((total - r) / world) streams) travels in the
+ * next message and all ranks return 0 together before the big all-gather -- nobody is left waiting in a collective.
+ * (Exception: a rank that cannot allocate the first 24 (world + 1) bytes of device memory.)  `comm` is the caller's
  * ncclComm_t, `stream` a hipStream_t (or NULL); every rank passes its n_local streams.  On `root`: *all / *all_len hold
  * the *n_all streams of the job in item order (free each with fiasco_amd_free(), the two arrays with free()); the other
  * ranks get *n_all = 0.  RCCL is taken from the process at run time (no link-time dependency).  1 ok / 0 + message.
@@ -86,8 +90,11 @@ int fiasco_amd_rccl_gather(void *comm, void *stream, int rank, int world, int ro
  * device, results in input order, no collective.  The devices are: FIASCO_AMD_DEVICES="0,1,..." from the
  * environment if set; else what fiasco_amd_set_devices() chose; else the ONE device of
  * fiasco_amd_set_device() (one process per GPU: the multi-process harness); else every visible device.
- * An id may be listed twice (two shares on one GPU).  Replacement of staged inputs
- * (fiasco_amd_batch_upload) needs a single device.  All return 1 on success, 0 + error message. */
+ * An id may be listed twice (two shares on one GPU).  Replacement of staged inputs (fiasco_amd_batch_upload) works
+ * with several devices too: one pinned host buffer, every share copies the planes of ITS frames.  Threading: the
+ * batch entries of ONE process may be called from several host threads, but calls that spread over more than one
+ * device share run one after the other (the shares' worker threads belong to the process, core_hip.cpp
+ * for_each_share).  All return 1 on success, 0 + error message. */
 /* workgroups per frame the launcher gives the table passes of `frames` big frames (prediction, P/B frames, -z 1/2)
  * on a chip of `cus` CUs: 1, 2, 4 or 8 (csrc/hip/frame_coder.h FcCoop); pure function */
 unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus);

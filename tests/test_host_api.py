@@ -65,11 +65,12 @@ def test_no_oracle_in_product():
     names = [line.split()[-1] for line in out.splitlines() if line.strip()]
     assert "fiasco_coder" in names and "fiasco_amd_core_name" in names
     # drop-in hygiene (csrc/exports.map): only the public names are dynamic symbols -- fiasco.h's API, the two
-    # symbols the reference CLI objects import and the fiasco_amd_* extensions; no fa_*, fc_*, device stubs
-    assert all(n.startswith("fiasco_") or n == "open_file" for n in names), [n for n in names if not n.startswith("fiasco_")]
-    # ... and the seam is still the HIP core's (static symbol table)
-    full = subprocess.run(["nm", fiasco_amd.LIB_PATH], capture_output=True, text=True).stdout
-    assert "fa_core_encode_frames" in full
+    # symbols the reference CLI objects import, the fiasco_amd_* extensions and the seam fa_core_* that INTEGRATION.md 3
+    # documents; no other fa_*, no fc_*, no device stubs
+    ok = lambda n: n.startswith("fiasco_") or n == "open_file" or n.startswith("fa_core_")
+    assert all(ok(n) for n in names), [n for n in names if not ok(n)]
+    # ... and the seam is the HIP core's
+    assert "fa_core_encode_frames" in names
     dump = open(fiasco_amd.LIB_PATH, "rb").read()
     assert b"oracle-cpu" not in dump and b"oracle_core" not in dump
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,6 +82,29 @@ def test_no_oracle_in_product():
             elif f.endswith((".c", ".cpp", ".hip")):        # sources: no include / link of it
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle_core" not in txt, f
+
+
+def test_reference_side_code_links_against_the_seam(product, tmp_path):
+    """a maintainer replaces subdivide() inside the reference tree by a call of the seam
+    (fa_core_encode_frames, or the staged fa_core_stage / _run / _submit / _finish2 / _unstage, and
+    fa_core_decode_frames for the reference frames of a video).  Such a build links libfiasco_amd.so: the seam must
+    be among its dynamic symbols (csrc/exports.map).  Link only -- nothing is called without a GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "seam_user.c"
+    src.write_text("""
+#include "fa_host.h"
+/* what a patched codec/coder.c would reference */
+void *seam[] = { (void *) fa_core_encode_frames, (void *) fa_core_stage, (void *) fa_core_run, (void *) fa_core_submit,
+                 (void *) fa_core_finish2, (void *) fa_core_finish, (void *) fa_core_unstage, (void *) fa_core_upload_buffer,
+                 (void *) fa_core_upload_commit, (void *) fa_core_decode_frames, (void *) fa_core_release_dev,
+                 (void *) fa_core_name };
+int main (void) { return seam[0] == 0; }
+""")
+    exe = str(tmp_path / "seam_user")
+    r = subprocess.run(["gcc", "-std=gnu99", "-I" + os.path.join(root, "fiasco_amd", "csrc", "host"), "-I" + os.path.join(root, "include"),
+                        "-o", exe, str(src), "-L" + os.path.dirname(fiasco_amd.LIB_PATH), "-lfiasco_amd",
+                        "-Wl,-rpath," + os.path.dirname(fiasco_amd.LIB_PATH)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_option_validation_messages(product):

@@ -44,7 +44,7 @@ extern "C" const char *fa_knob(const char *name)
  * rank of the multi-process harness after fiasco_amd_set_device()) uses g_state0 from whatever thread
  * calls in.  The multi-device entries at the end of this file give every further device a DevState of its
  * own and run its share of a batch on a host thread whose t_dev points there. */
-struct PoolEntry { char *base; size_t bytes; };
+struct PoolEntry { char *base; size_t bytes; int device; };   /* device: where hipMalloc gave the slab out (checked on every acquire) */
 struct Log2Patch { unsigned *d_keys = nullptr; double *d_vals = nullptr; unsigned mask = 0; int device = -1;
                    unsigned long long entries = 0; bool tried = false, ok = false; };
 struct DevState {
@@ -219,6 +219,8 @@ static unsigned coop_policy(size_t frames, int cus)
     return 1;
 }
 extern "C" unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus) { return coop_policy(frames, cus); }
+/* the dealing function of the device shares (fa_host.h), for the tests: job -> share is a function of the key alone */
+extern "C" unsigned fiasco_amd_share_of(unsigned share_key, unsigned index, unsigned shares) { return fa_share_of(share_key, index, shares); }
 extern "C" int fiasco_amd_spec_workgroups(unsigned frames, int cus, int big_frames, int narrow_only, int occupancy)
 {
     return spec_policy(frames, cus, big_frames != 0, narrow_only != 0, occupancy);
@@ -527,11 +529,29 @@ static bool log2_patch_build(void)
 /* ------------------------------------------------------------------ slab pool */
 
 
+/* the current device of the calling thread (the share's, bind_share); -1 when HIP cannot tell */
+static int pool_device(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void) hipGetLastError(); d = -1; }
+    return d;
+}
+
 static char *slab_acquire(size_t bytes, size_t *got)
 {
+    /* A slab never meets another device: the pool belongs to a share (t_dev), a share to a device.  An entry whose
+     * tag says otherwise (a device list changed under a pool, a share bound to the wrong device) is a bug of the
+     * launcher -- such an entry is not handed out, the call allocates afresh and says so. */
+    const int here = pool_device();
     size_t best = g_free.size();
     for (size_t i = 0; i < g_free.size(); i++)
-        if (g_free[i].bytes >= bytes && g_free[i].bytes <= bytes + bytes / 4
+        if (g_free[i].device != here && g_free[i].device >= 0 && here >= 0) {
+            static bool told = false;
+            if (!told) { told = true; fprintf(stderr, "libfiasco_amd: slab pool entry of device %d met device %d (not used)\n", g_free[i].device, here); }
+        }
+    for (size_t i = 0; i < g_free.size(); i++)
+        if ((g_free[i].device == here || g_free[i].device < 0 || here < 0)
+            && g_free[i].bytes >= bytes && g_free[i].bytes <= bytes + bytes / 4
             && (best == g_free.size() || g_free[i].bytes < g_free[best].bytes))
             best = i;
     if (best != g_free.size()) {
@@ -560,7 +580,7 @@ static char *slab_acquire(size_t bytes, size_t *got)
 
 static void slab_release(char *p, size_t bytes)
 {
-    if (p) g_free.push_back(PoolEntry{p, bytes});
+    if (p) g_free.push_back(PoolEntry{p, bytes, pool_device()});
 }
 
 /* ------------------------------------------------------------------ layout */
@@ -2308,8 +2328,9 @@ extern "C" void fiasco_amd_reset_stats(void)
 struct MultiStaged {
     unsigned n = 0;
     fa_job  *jobs = nullptr;
-    struct Part { std::vector<unsigned> idx; std::vector<fa_job> sub; void *staged = nullptr; int good = 0; };
-    std::vector<Part> parts;        /* one share: parts[0].staged works on jobs[] itself, nothing is copied */
+    struct Part { std::vector<unsigned> idx; std::vector<fa_job> sub; void *staged = nullptr; int good = 0;
+                  size_t share = 0;   /* the device share (g_devices / g_dev_state index) this part runs on */ };
+    std::vector<Part> parts;        /* one part: parts[0].staged works on jobs[] itself, nothing is copied */
     char  *up_host = nullptr;       /* several shares: the pinned buffer of fa_core_upload_buffer (the shares borrow it) */
     size_t up_host_bytes = 0;
 };
@@ -2347,7 +2368,7 @@ static void *share_worker_main(void *p)
         while (w->state != 1) pthread_cond_wait(&w->cv, &w->mu);
         pthread_mutex_unlock(&w->mu);
         bind_share(w->k);
-        w->call(w->ctx, w->k);
+        w->call(w->ctx, w->k);                 /* ctx names the part of the batch (for_shares) */
         pthread_mutex_lock(&w->mu);
         w->state = 2;
         pthread_cond_broadcast(&w->cv);
@@ -2374,28 +2395,33 @@ static ShareWorker *share_worker(size_t k)
 /* run fn(share) for every share: share 0 on the calling thread, the others on their workers; EVERY share --
  * also the only one of a call -- runs bound to its device g_devices[k] with the DevState of that share (the slab
  * pool of a share never sees another device), and the caller's current device is what it was afterwards */
-template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
+template <typename Fn> static void for_shares(const std::vector<size_t> &share, Fn fn)
 {
-    const size_t D = M->parts.size();
+    const size_t D = share.size();
     int cur = -1;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     if (!have_cur) (void) hipGetLastError();
     /* the workers' call / ctx / state slots are per process: two host threads driving two multi-share batches
      * would overwrite each other's task (a lost task, or a wait for `state == 2' that never ends) */
     if (D > 1) pthread_mutex_lock(&g_share_lock);
-    auto tramp = [](void *p, size_t k) { (*(Fn *) p)(k); };
+    struct Task { Fn *fn; size_t part; };
+    std::vector<Task> task(D);
+    auto tramp = [](void *p, size_t) { Task *t = (Task *) p; (*t->fn)(t->part); };
     std::vector<ShareWorker *> posted(D, nullptr);
     for (size_t k = 1; k < D; k++) {
-        ShareWorker *w = share_worker(k);
+        /* part k on the worker of ITS share; two parts of one share (never dealt that way) would run one after the other */
+        bool dup = false;
+        for (size_t j = 0; j < k; j++) dup = dup || share[j] == share[k];
+        ShareWorker *w = dup ? nullptr : share_worker(share[k]);
         if (!w) continue;
+        task[k].fn = &fn; task[k].part = k;
         pthread_mutex_lock(&w->mu);
-        w->call = tramp; w->ctx = &fn; w->state = 1;
+        w->call = tramp; w->ctx = &task[k]; w->state = 1;
         pthread_cond_broadcast(&w->cv);
         pthread_mutex_unlock(&w->mu);
         posted[k] = w;
     }
-    bind_share(0);
-    fn(0);
+    if (D) { bind_share(share[0]); fn(0); }
     for (size_t k = 1; k < D; k++) {
         if (posted[k]) {
             ShareWorker *w = posted[k];
@@ -2403,7 +2429,7 @@ template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
             while (w->state != 2) pthread_cond_wait(&w->cv, &w->mu);
             w->state = 0;
             pthread_mutex_unlock(&w->mu);
-        } else { bind_share(k); fn(k); }             /* no thread: one after the other */
+        } else { bind_share(share[k]); fn(k); }      /* no thread: one after the other */
     }
     if (D > 1) pthread_mutex_unlock(&g_share_lock);
     t_dev = &g_state0;
@@ -2413,16 +2439,43 @@ template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
     }
 }
 
+/* fn(part) for every part of a staged batch, each on the share it was dealt to */
+template <typename Fn> static void for_each_share(MultiStaged *M, Fn fn)
+{
+    std::vector<size_t> share(M->parts.size());
+    for (size_t k = 0; k < share.size(); k++) share[k] = M->parts[k].share;
+    for_shares(share, fn);
+}
+
 extern "C" void *fa_core_stage(unsigned n, fa_job *jobs)
 {
     resolve_devices();
     MultiStaged *M = new MultiStaged;
     M->n = n; M->jobs = jobs;
     size_t D = g_devices.size();
-    if (D > n) D = n ? n : 1;
-    M->parts.resize(D);
-    if (D == 1) { for_each_share(M, [&](size_t) { M->parts[0].staged = core1_stage(n, jobs); }); return M; }
-    for (unsigned i = 0; i < n; i++) M->parts[i % D].idx.push_back(i);       /* round robin, SURVEY 8e */
+    bool keyed = false;
+    for (unsigned i = 0; i < n; i++) keyed = keyed || jobs[i].share_key != 0;
+    /* jobs without a key: round robin over as many shares as there are jobs.  Jobs with a key (the GOP
+     * of a video, fa_host.h fa_share_of): the share is a function of the key and of the number of devices ALONE -- not
+     * of how many jobs this call happens to hold --, shares without a job get no part */
+    if (!keyed && D > n) D = n ? n : 1;
+    if (D == 1) { M->parts.resize(1); for_each_share(M, [&](size_t) { M->parts[0].staged = core1_stage(n, jobs); }); return M; }
+    {
+        std::vector<MultiStaged::Part> all(D);
+        for (unsigned i = 0; i < n; i++) all[fa_share_of(jobs[i].share_key, i, (unsigned) D)].idx.push_back(i);
+        size_t used = 0, only = 0;
+        for (size_t k = 0; k < D; k++) if (!all[k].idx.empty()) { used++; only = k; }
+        if (used <= 1) {
+            /* every job on one share (the last GOPs of a video): ONE part that works on jobs[] itself, on that share */
+            M->parts.resize(1);
+            M->parts[0].share = used ? only : 0;
+            for_each_share(M, [&](size_t) { M->parts[0].staged = core1_stage(n, jobs); });
+            return M;
+        }
+        for (size_t k = 0; k < D; k++)
+            if (!all[k].idx.empty()) { all[k].share = k; M->parts.push_back(all[k]); }
+    }
+    D = M->parts.size();
     for (size_t k = 0; k < D; k++) {
         MultiStaged::Part &P = M->parts[k];
         P.sub.resize(P.idx.size());

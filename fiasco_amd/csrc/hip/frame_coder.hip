@@ -3797,8 +3797,14 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
           unsigned long long queue_wait_ticks, unsigned coopW)
 #endif
 {
-    /* the LDS budget of the build: FC_WG_PER_CU workgroups share the 160 KB of a CU (the few words beside Sh included) */
-    static_assert(sizeof(Sh) + 256 <= (160u * 1024u) / FC_WG_PER_CU, "Sh outgrows the LDS share of a workgroup of this build");
+    /* the LDS budget of the build: FC_WG_PER_CU workgroups share the 160 KB of a CU.  Beside Sh the kernel keeps a few
+     * words (and, speculating builds, one SpecLocal): the big 256-thread build is at 81 736 of its 81 920 bytes */
+#if FC_SPEC
+    constexpr unsigned FC_LDS_EXTRA = sizeof(Sh::SpecLocal) + 64;
+#else
+    constexpr unsigned FC_LDS_EXTRA = 64;
+#endif
+    static_assert(sizeof(Sh) + FC_LDS_EXTRA <= (160u * 1024u) / FC_WG_PER_CU, "Sh outgrows the LDS share of a workgroup of this build");
     __shared__ Sh sh;
 #if FC_SPEC
     __shared__ Sh::SpecLocal sl_keep;

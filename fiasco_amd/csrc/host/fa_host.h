@@ -164,6 +164,7 @@ typedef struct fa_dec_job {
     unsigned        p_max_level;          /* in  */
     int             skip;                 /* in: leave this job alone (keeps the index -> device dealing) */
     int             keep_dev;             /* in: leave the planes on the device too (out->dev): reference frames */
+    unsigned        share_key;            /* in: as fa_job.share_key (0 = dealt by index) */
     fa_image       *out;                  /* out: the frame, or NULL + errmsg */
     char            errmsg[160];
 } fa_dec_job;
@@ -250,7 +251,20 @@ typedef struct fa_job {
                                      show through on states of the next frame that are not made
                                      by init_new_state (the three join states).  On return the
                                      array holds this frame's flags for EVERY state id. */
+    unsigned          share_key;  /* in: 0 = none, else key + 1: jobs with the same key go to the same device share of
+                                     the process whatever their index in the call (fa_share_of) -- the sequence engine
+                                     passes the GOP number, so that the frames of a GOP and the decoded reference
+                                     frames between them stay on ONE device while other GOPs end */
 } fa_job;
+
+/* Which of `shares' device shares (core_hip.cpp: one per device of the process) takes a job: a pure function of the
+ * job's key when it has one, of its index in the call otherwise (round robin).  The search
+ * (fa_core_stage) and the decoder (fa_core_decode_frames) both deal with it, so a keyed job is decoded where its
+ * successor is searched. */
+static inline unsigned fa_share_of(unsigned share_key, unsigned index, unsigned shares)
+{
+    return shares ? (share_key ? share_key - 1u : index) % shares : 0u;
+}
 
 /* THE SEAM.  Encode n independent frames.  Returns number of successful jobs.
  * Staged form: stage() makes the inputs resident where the core computes (HBM for the HIP

@@ -304,6 +304,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
             jobs[nb].image = ims[nb];
             jobs[nb].cp = s->cp;
             jobs[nb].cp.lc_min_level = q->carry;
+            jobs[nb].share_key = q->g + 1;         /* a GOP stays on one device share whatever its index in this step's batch */
             if (nb == 0 && step == 0 && q->g == 0 && s->probe_wfa && q->carry == s->cp.lc_min_level && type == FA_I_FRAME) {
                 /* the probe was this very search: its result stands in for the job (entry 0, not sent to the core) */
                 jobs[nb].frame_type = type;
@@ -368,6 +369,7 @@ int fa_seq_search(fa_seq *s, const unsigned *carry_in, const uint8_t *todo)
                 const unsigned k = s->gfirst[q->g] + step;
                 memset(&djobs[b], 0, sizeof djobs[b]);
                 djobs[b].skip = !need[b]; djobs[b].keep_dev = 1;
+                djobs[b].share_key = q->g + 1;     /* ... and its reference frames are decoded there */
                 if (!need[b]) continue;
                 any = 1;
                 djobs[b].wfa = s->wfa[k]; djobs[b].width = s->wi.width; djobs[b].height = s->wi.height;

@@ -98,6 +98,12 @@ int fiasco_amd_rccl_gather(void *comm, void *stream, int rank, int world, int ro
 /* workgroups per frame the launcher gives the table passes of `frames` big frames (prediction, P/B frames, -z 1/2)
  * on a chip of `cus` CUs: 1, 2, 4 or 8 (csrc/hip/frame_coder.h FcCoop); pure function */
 unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus);
+/* which of `shares` device shares of the process takes a job (a pure function, no device): share_key == 0 -> the job's
+ * index in the call, round robin (frames of a batch); share_key = key + 1 -> key mod shares whatever the
+ * index and however many jobs the call holds.  The sequence engine keys the frames of a video and the decodes of their
+ * reference frames by their group of pictures, so a GOP never changes its device (codec/coder.c:490-668 is the loop
+ * that is sharded; the reference has one device: the host). */
+unsigned fiasco_amd_share_of(unsigned share_key, unsigned index, unsigned shares);
 int fiasco_amd_set_device(int device);
 int fiasco_amd_set_devices(const int *ids, int n);      /* n = 0: back to the automatic choice */
 int fiasco_amd_device_count(void);                      /* shares a batch is split into */

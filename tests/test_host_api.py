@@ -59,6 +59,28 @@ def test_workgroups_for_the_tables_of_big_frames(product):
     assert [f(n, 64) for n in (1, 8, 9, 16, 17, 32, 33)] == [8, 8, 4, 4, 2, 2, 1]
 
 
+def test_jobs_of_a_gop_are_dealt_by_the_gop_not_by_their_place_in_the_call(product):
+    """Multi-device hygiene (a 1-GPU box cannot run it, a pure function can be checked
+    anywhere): the device share of a job is fa_share_of(key, index, shares) (csrc/host/fa_host.h) for the search
+    (fa_core_stage) and for the decoder (fa_core_decode_frames) alike.  Without a key: round robin by index.  With a
+    key -- the sequence engine passes the GOP number for every frame of a video and for the decode of its reference
+    frames (fa_sequence.c) --: a function of the key and the number of devices ALONE, so a GOP keeps its device when
+    earlier GOPs end, when the probe's result stands in for job 0, and whatever the size of the step's batch."""
+    f = product.L.fiasco_amd_share_of
+    f.restype = ctypes.c_uint
+    f.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    for shares in (1, 2, 3, 8):
+        assert [f(0, i, shares) for i in range(20)] == [i % shares for i in range(20)]
+        for gop in range(40):
+            assert {f(gop + 1, i, shares) for i in range(64)} == {gop % shares}      # the index does not matter
+    # 30 GOPs on 8 devices: steps in which GOPs 0..4 have ended (shorter GOPs) -- the others stay where they were
+    full = {g: f(g + 1, g, 8) for g in range(30)}
+    later = {g: f(g + 1, i, 8) for i, g in enumerate(range(5, 30))}
+    assert all(later[g] == full[g] for g in later)
+    assert sorted(set(full.values())) == list(range(8))                              # and all devices are used
+    assert f(5, 3, 0) == 0
+
+
 def test_no_oracle_in_product():
     """The product library must not link or contain the CPU oracle."""
     out = subprocess.run(["nm", "-D", "--defined-only", fiasco_amd.LIB_PATH], capture_output=True, text=True).stdout

@@ -212,6 +212,15 @@ enum { PH_ENTER = 0, PH_AFTER_INIT, PH_AFTER_LC, PH_CHILD, PH_CHILD2, PH_CHILD_R
        PH_AFTER_APPEND, PH_PRED_BEGIN, PH_PRED_RECURSE, PH_PRED_RET, PH_PRED_DONE, PH_PRED_MC2, PH_PRED_GO,
        PH_SPEC_END };
 enum { MV_NONE = 0, MV_FORWARD = 1, MV_BACKWARD = 2, MV_INTERPOLATED = 3 };
+/* FC_DUP_OP=<op>: developer build that runs one of the idempotent table operations (OP_INIT_RANGE, OP_APPEND,
+ * OP_IPIS_INCR: they write a function of what they read, the second run writes the same values) TWICE: the difference
+ * of the PMC traffic counters to the plain build is that operation's HBM traffic (tests/gpu_traffic_by_op.sh,
+ * profiles/r06_traffic_by_op.txt).  Same streams; the roofline counters of the op count double. */
+#ifdef FC_DUP_OP
+#define FC_DUP(o, call) do { if ((o) == FC_DUP_OP) { __syncthreads(); call; } } while (0)
+#else
+#define FC_DUP(o, call) do { } while (0)
+#endif
 #if FC_VARIANT_BIG
 #define FC_DEPTH FC_MAXDEPTH_BIG
 #elif FC_VARIANT_WIDE
@@ -4403,11 +4412,11 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             op_init_range(F, sh, sh.a0, sh.a1, sh.tab_from);
             break;
 #else
-        case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1, 0); break;
+        case OP_INIT_RANGE: op_init_range(F, sh, sh.a0, sh.a1, 0); FC_DUP(OP_INIT_RANGE, op_init_range(F, sh, sh.a0, sh.a1, 0)); break;
 #endif
         case OP_APPROX:     op_approx(F, sh); break;
-        case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); break;
-        case OP_APPEND:     op_append(F, sh, sh.a0); break;
+        case OP_IPIS_INCR:  op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3); FC_DUP(OP_IPIS_INCR, op_ipis(F, sh, sh.a0, sh.a1, sh.a2, sh.a3)); break;
+        case OP_APPEND:     op_append(F, sh, sh.a0); FC_DUP(OP_APPEND, op_append(F, sh, sh.a0)); break;
         case OP_CHROMA:
             op_chroma_pool(F, sh);
 #if FC_SPEC

@@ -105,20 +105,23 @@ def cpu_baseline(frame_pnm, w, h):
     return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "cpu coder unavailable"}
 
 
-def pmc_traffic(frames, w, h):
+def pmc_traffic(frames, w, h, colour=False):
     """HBM bytes per launch from the PMC passes of tests/gpu_profile.sh (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs of this same command), committed under profiles/.
-    Counters cannot be collected from inside the timed run; the figure is reported only for
-    the workload it was measured on."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    FETCH_SIZE / WRITE_SIZE, separate runs of the same workload), committed under profiles/.
+    Counters cannot be collected from inside the timed run: the figure is STATIC -- measured on
+    another run of the same kernel build, reported only for the workload it was measured on -- and
+    the JSON line says so (`traffic_source`).  Returns (bytes or None, source or None)."""
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         for e in (j if isinstance(j, list) else [j]):
-            if (frames, w, h) == (e.get("frames_per_launch", 768), e.get("width", 1920), e.get("height", 1080)):
-                return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
-    return None
+            if (frames, w, h, bool(colour)) == (e.get("frames_per_launch", 768), e.get("width", 1920), e.get("height", 1080), bool(e.get("colour", False))):
+                return (e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"],
+                        "profiles/%s (static: rocprofv3 --pmc FETCH_SIZE x %g + WRITE_SIZE, separate passes over this workload "
+                        "and kernel build, not collected in this run)" % (name, e.get("fetch_correction", 1.0)))
+    return None, None
 
 
 def small_launches(lib, opt, uniq, w, h):
@@ -216,7 +219,8 @@ def k4_pass(lib, nframes, rank):
             "kernel_only_frames_per_s": st.frames / ks if ks else None, "launches": int(st.launches),
             "reencoded_frames": int(st.reencodes), "frames_by_kernel_build": list(st.frames_by_build),
             "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9 if ks else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": pmc_traffic(nframes, w, h),
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": pmc_traffic(nframes, w, h)[0],
+                         "traffic_source": pmc_traffic(nframes, w, h)[1],
                          "kernel": "fiasco_frame_kernel_wide_tri", "avg_launch_ms": st.kernel_ms / max(st.launches, 1),
                          "algorithmic_bytes_per_launch": alg / max(st.launches, 1)},
             "parity": ("stream md5 of survey frame == patched reference (%s)" % md5[:12])
@@ -319,7 +323,8 @@ def config3_pass(lib, nframes):
             "kernel_seconds": ks, "launches": int(st.launches), "reencoded_frames": int(st.reencodes),
             "frames_by_kernel_build": list(st.frames_by_build), "states_max": int(st.states_max),
             "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9 if ks else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None, "traffic": None},
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBS if ks else None,
+                         "traffic": pmc_traffic(nframes, 1920, 1080, True)[0], "traffic_source": pmc_traffic(nframes, 1920, 1080, True)[1]},
             "parity": ("frame 0 == patched reference (%s)" % md5[:12]) if md5 and md5.startswith(REF_MD5_K1080) else "MISMATCH: %s" % md5,
             "generate_seconds": t_gen}
 
@@ -684,7 +689,8 @@ def main():
                        "small_launches": small if not dry else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                         "traffic": pmc_traffic(F, a.width, a.height),
+                         "traffic": pmc_traffic(F, a.width, a.height)[0],
+                         "traffic_source": pmc_traffic(F, a.width, a.height)[1],
                          "kernel": ("fiasco_frame_kernel_spec" + ("_wide" if max(a.width, a.height) > 2048 else "")
                                     if st is not None and st.spec_frames else "fiasco_frame_kernel"),
                          "avg_launch_ms": avg_kernel_s * 1e3,

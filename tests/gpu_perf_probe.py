@@ -51,6 +51,7 @@ for r in range(reps):
              st.n_mp // max(ok, 1), st.n_steps // max(ok, 1), st.n_fulleval // max(ok, 1)))
     print("  mp: phaseA %.1f%% phaseB %.1f%% of frame; block evals/call %.2f, full evals/call %.1f"
           % (100.0 * st.t_mpA / tt, 100.0 * st.t_mpB / tt, st.n_blockevals / max(st.n_mp, 1), st.n_fulleval / max(st.n_mp, 1)))
+    print("  per frame: blocks %d appends %d block-evals %d" % (st.n_blocks // max(ok, 1), st.n_appends // max(ok, 1), st.n_blockevals // max(ok, 1)))
     print("  states: avg %.0f max %d; re-encoded frames %d; frames per build (256/1024/big256/big512/1024tri): %s"
           % (st.states_sum / max(ok, 1), st.states_max, st.reencodes, list(st.frames_by_build)))
     if any(st.dbg):

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fiasco_amd_get_limits", "fiasco_amd_encode_batch", "fiasco_amd_free",
     "fiasco_amd_get_stats", "fiasco_amd_reset_stats", "fiasco_amd_spec_workgroups", "fiasco_amd_core_name", "fiasco_amd_rccl_gather", "fiasco_amd_set_device",
     "fiasco_amd_batch_stage", "fiasco_amd_batch_encode", "fiasco_amd_batch_free",
-    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_batch_decode_psnr_all", "fiasco_amd_coop_workgroups", "fiasco_amd_share_of", "fiasco_amd_batch_decode_plane", "fiasco_amd_c_options_set_models",
+    "fiasco_amd_batch_submit", "fiasco_amd_batch_collect", "fiasco_amd_batch_stats", "fiasco_amd_batch_decode_psnr", "fiasco_amd_batch_decode_psnr_all", "fiasco_amd_coop_workgroups", "fiasco_amd_share_of", "fiasco_amd_spec_append_helpers", "fiasco_amd_batch_decode_plane", "fiasco_amd_c_options_set_models",
     "fiasco_amd_release_memory", "fiasco_amd_batch_upload", "fiasco_amd_set_devices", "fiasco_amd_device_count",
     "fiasco_amd_selftest_log2", "fiasco_amd_selftest_log2_patched",
     "fiasco_amd_selftest_log2_max_ulp",
@@ -69,7 +69,8 @@ class Stats(ctypes.Structure):
                 ("spec_tab_missed", ctypes.c_ulonglong), ("spec_adopted", ctypes.c_ulonglong),
                 ("decoder_frames", ctypes.c_ulonglong), ("decoder_bytes", ctypes.c_ulonglong),
                 ("decoder_us", ctypes.c_ulonglong), ("coop_frames", ctypes.c_ulonglong),
-                ("coop_workgroups", ctypes.c_ulonglong)]
+                ("coop_workgroups", ctypes.c_ulonglong),
+                ("spec_app_rows", ctypes.c_ulonglong), ("spec_app_wait", ctypes.c_ulonglong)]
 
 
 def build(verbose=False):

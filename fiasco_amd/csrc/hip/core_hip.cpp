@@ -79,11 +79,11 @@ extern "C" void fc_launch_big_gm(DevFrame *d_frames, unsigned n, unsigned nlend,
                        const unsigned *ptrmask, unsigned long long queue_wait_ticks, unsigned coopW, hipStream_t stream);
 
 /* block-level speculation (frame_coder.h, FcSpecCtl): n frames with G workgroups each */
-extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
+extern "C" void fc_launch_spec(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, unsigned H, hipStream_t stream);
 extern "C" unsigned fc_spec_slot_bytes(void);
 extern "C" unsigned fc_spec_ctl_bytes(void);
 extern "C" int fc_occupancy_spec(void);
-extern "C" void fc_launch_spec_wide(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream);
+extern "C" void fc_launch_spec_wide(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, unsigned H, hipStream_t stream);
 extern "C" unsigned fc_spec_slot_bytes_wide(void);
 
 /* which of the two kernel builds (frame_coder.hip) encodes a job: the default build covers
@@ -676,8 +676,12 @@ static int device_supported(const fa_job *job, char *why, size_t n)
         snprintf(why, n, "Motion search without a reference frame (frame pattern).");
         return 0;
     }
-    if ((cp->prediction || job->frame_type != FA_I_FRAME) && cp->p_max_level - cp->lc_min_level + 1 > 9) {
-        snprintf(why, n, "prediction over more than 9 block levels is not supported by the device coder");
+    /* (signed: after a colour frame the minimum block level may have been ratcheted ABOVE the prediction window --
+     * codec/coder.c:785-797 -- which then holds no level at all; found by tests/test_gpu_fuzz_reference.py, seed 71064:
+     * the unsigned difference refused a P frame the reference codes) */
+    if ((cp->prediction || job->frame_type != FA_I_FRAME) && (int) cp->p_max_level - (int) cp->lc_min_level + 1 > 9) {
+        snprintf(why, n, "prediction over more than 9 block levels is not supported by the device coder (levels %u .. %u, frame type %d)",
+                 cp->lc_min_level, cp->p_max_level, job->frame_type);
         return 0;
     }
     if (cp->images_level != 5 || cp->lc_min_level < 4) {
@@ -805,6 +809,8 @@ struct Staged {
      * workgroups, and one buffer with -- per frame -- control block + checkpoint slots, then the
      * verifiers' private tables */
     int       specG = 0;
+    int       specH[2] = { 0, 0 };    /* append helpers per frame of the launch in flight, per workgroup width (FcSpecCtl.app_*) */
+    bool      no_app = false;         /* the append helpers of a frame did not answer (FC_ERR_COOP): none from here on */
     DevFrame *d_vframes = nullptr;
     size_t    vframes_n = 0;
     char     *d_spec = nullptr;
@@ -848,6 +854,34 @@ static void spec_block_list(const DevFrame &F, std::vector<uint16_t> &out)
 }
 
 static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ);
+
+/* Append helpers per frame (frame_coder.h FcSpecCtl.app_*): further workgroups of a speculating frame that build their
+ * shares of every Gram row the chain appends.  For the 1024-thread speculating build (frames beyond 3072 states: 4K),
+ * whose launches give a frame a CU per workgroup and leave the rest of the chip empty -- BASELINE config 4 as written
+ * puts 8 frames on a GPU: 8 x 8 workgroups on 256 CUs -- and whose rows are long (up to 10 passes of the 1024 lanes).
+ * As many as the chip has CUs left for, at most 7; fewer than 2 are not worth the hand-off.  A function of its arguments
+ * alone (fiasco_amd_spec_append_helpers); FIASCO_AMD_SPEC_APP=<H> (tests, experiments) asks for H, also in the
+ * 256-thread build. */
+static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int occ)
+{
+    if (!frames || G < 2 || cus < 1) return 0;
+    if (occ < 1) occ = 1;
+    const size_t room = (size_t) cus * (size_t) occ / frames;       /* workgroups per frame that can be resident */
+    size_t H = room > (size_t) G ? room - (size_t) G : 0;
+    const char *e = fa_knob("FIASCO_AMD_SPEC_APP");
+    if (e) { const size_t want = (size_t) (atoi(e) > 0 ? atoi(e) : 0); return (int) (want < H ? want : H); }
+    if (!wide_build) return 0;
+    /* 4K frames slow each other down once more than half the CUs work on them (spec_policy): the helpers stay inside
+     * that half */
+    const size_t half = (size_t) cus / (2 * frames);
+    H = half > (size_t) G ? half - (size_t) G : 0;
+    if (H > 7) H = 7;
+    return H >= 2 ? (int) H : 0;
+}
+extern "C" int fiasco_amd_spec_append_helpers(unsigned frames, int cus, int G, int wide_build)
+{
+    return spec_app_policy(frames, cus, G, wide_build != 0, 1);
+}
 
 static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only)
 {
@@ -1759,6 +1793,12 @@ static bool launch_wave(Staged *S)
         const int G = S->specG;
         const int T = spec_workers(G), NV = G - 1 - T;           /* table workers, verifiers */
         const size_t nall = group_n[7] + group_n[8], first_all = batch.size() - nall;
+        /* append helpers: only a launch of ONE width (the residency sum below is per build) */
+        S->specH[0] = S->specH[1] = 0;
+        if (!S->no_app) {
+            if (group_n[8] && !group_n[7]) S->specH[1] = spec_app_policy(group_n[8], S->ncu, G, true, 1);
+            else if (group_n[7] && !group_n[8]) S->specH[0] = spec_app_policy(group_n[7], S->ncu, G, false, fc_occupancy_spec());
+        }
         S->spec_first[0] = first_all; S->spec_n[0] = group_n[7];
         S->spec_first[1] = first_all + group_n[7]; S->spec_n[1] = group_n[8];
         /* one span for every frame of the launch (sized for the largest) */
@@ -1849,6 +1889,12 @@ static bool launch_wave(Staged *S)
                  * makes it take the worker's tables only when they are there already) */
                 h.tab_wait = fa_knob("FIASCO_AMD_SPEC_TABWAIT") ? (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_TABWAIT")) : 12000u;
                 h.off_blocks = off_blocks; h.off_tabs = off_tabs;
+                {   /* append helpers of the frame's width group (frames of the 256-thread build come first) */
+                    const int wk = i < group_n[7] ? 0 : 1;
+                    h.app_H = (unsigned) S->specH[wk];
+                    h.app_min = wk ? 2048u : 512u;               /* two passes of the workgroup's lanes */
+                    h.app_wait = fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS") ? 100000u * (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS")) : 200000000u;   /* 2 s */
+                }
                 fail = hipMemcpy(S->d_spec + span * i, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess;
                 if (!fail && !lists[i].empty())
                     fail = hipMemcpy(S->d_spec + span * i + off_blocks, lists[i].data(), lists[i].size() * 2, hipMemcpyHostToDevice) != hipSuccess;
@@ -1876,7 +1922,7 @@ static bool launch_wave(Staged *S)
             const size_t all_first = S->spec_first[0];
             DevFrame *vfr = S->d_vframes ? S->d_vframes + (S->spec_first[k] - all_first) * (size_t) (S->specG - 1) : nullptr;
             (k ? fc_launch_spec_wide : fc_launch_spec)(S->d_frames + S->spec_first[k], vfr, (unsigned) S->spec_n[k],
-                                                       on ? (unsigned) S->specG : 1u, S->stream);
+                                                       on ? (unsigned) S->specG : 1u, on ? (unsigned) S->specH[k] : 0u, S->stream);
         }
         for (int g = 0; g < 7 && !fail; g++) {
             size_t plain = group_n[g], at = first;
@@ -1971,6 +2017,7 @@ static void complete_wave(Staged *S)
                 g_stats.spec_inline += ctl[i].n_inline; g_stats.spec_wait += ctl[i].t_wait;
                 g_stats.spec_tab_used += ctl[i].n_tab_used; g_stats.spec_tab_missed += ctl[i].n_tab_missed;
                 g_stats.spec_adopted += ctl[i].n_adopted;
+                g_stats.spec_app_rows += ctl[i].n_app_dealt; g_stats.spec_app_wait += ctl[i].t_app_wait;
             }
         else (void) hipGetLastError();
     }
@@ -2066,6 +2113,11 @@ static void complete_wave(Staged *S)
             if (fs.PA < fs.P) fs.PA = fs.P;
             if (fs.P > 12 * 1024) fs.spec = false;     /* beyond the speculating builds: one (wide) workgroup */
             if (!stage_slot(S, fs)) fs.done = true;
+            continue;
+        }
+        if (st == FC_ERR_COOP && fs.spec && !S->no_app) {
+            /* the append helpers of a speculating frame did not answer in time: again without helpers */
+            S->no_app = true;
             continue;
         }
         if (st == FC_ERR_COOP && !S->no_coop_done) {

@@ -306,6 +306,27 @@ typedef struct FcSpecCtl {
     unsigned tab_seq[FC_SPEC_R];    /* block index + 1 once the buffer holds that block's tables */
     unsigned tab_s[FC_SPEC_R];      /* ... for the states below this */
     unsigned tab_epoch[FC_SPEC_R];  /* ... read in this epoch or later */
+    /* Append helpers (round 6).  A third of what is left to the chain of a speculating 4K frame is the Gram row of every
+     * state it appends (codec/control.c:48-131, codec/ip.c:184-260): entries t = 0 .. s of the row are independent --
+     * each is a function of older rows, of the automaton rows of s and t and of the level-images_level images alone;
+     * codec/ip.c:213-257 fixes the order of operations per ENTRY, not the order of entries -- and one CU's gather rate
+     * bounds them.  app_H further workgroups of the frame (launched behind the chains / workers / verifiers of the
+     * launch, frame_coder.hip spec_append_helper) take the entries t with (t / B) mod (app_H + 1) == h + 1 of every
+     * row the chain publishes: term lists of the new state -> release -> app_seq; helpers: acquire, build, release ->
+     * app_done.  The chain builds its own share meanwhile and waits for app_seq * app_H arrivals -- bounded (app_wait): a
+     * frame whose helpers do not answer fails with FC_ERR_COOP and is searched again without helpers (a helper that
+     * turned up later could otherwise write into a row the chain has re-made since).  Same operations per entry, so
+     * the same values. */
+    unsigned app_H;                 /* helpers of this frame (host; 0: none) */
+    unsigned app_min;               /* rows with fewer entries than this are the chain's alone (host) */
+    unsigned app_wait;              /* ticks (100 MHz) the chain waits for its helpers before it gives the frame up (host) */
+    unsigned app_seq;               /* rows published by the chain */
+    unsigned app_done;              /* arrivals of the helpers (cumulative) */
+    unsigned app_off;               /* the chain has given up: helpers go home */
+    int      app_s, app_flim;       /* the row: state id; sh.flim of the chain */
+    int      app_n[2], app_c[2], app_idx[2][FC_MAXED + 1];      /* Sh::gs_n, gs_c, gs_idx, gs_w of the new state */
+    float    app_w[2][FC_MAXED + 1];
+    unsigned long long n_app_dealt, t_app_wait;                  /* statistics (chain): rows dealt, ticks waited for helpers */
 } FcSpecCtl;
 
 /* automaton row of one state, as store_state_data keeps it */

@@ -498,6 +498,9 @@ struct Sh {
         unsigned  nlc;
         float     learn;           /* costs of a combination that won in a search of the chain's own, not yet in mlc */
         unsigned long long n_tasks, n_confirmed, n_wrong, n_timeout, n_inline, t_wait;
+        /* chain: append helpers (FcSpecCtl.app_*): how many, from which row length, rows published, given up */
+        unsigned  app_H, app_min, app_seq, app_off;
+        unsigned long long n_app_dealt, t_app_wait;
     } sl;
 #endif
 };
@@ -1474,66 +1477,15 @@ __device__ void pred_save_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, 
 __device__ void subtract_mc_dev(DevFrame &__restrict__ F, Sh &__restrict__ sh);
 #endif
 
-/* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
-__device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
+/* Gram row of the new state s at every table level -- the entries t with (t / B) mod parts == part (all of them:
+ * part 0 of 1); level q needs level q-1 of states < s.  The term lists of s are in sh.gs_*.  Out of op_append so that
+ * the append helpers of a speculating frame (FcSpecCtl.app_*) run the same code on their shares. */
+__device__ __forceinline__ void append_row_part(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s, int part, int parts)
 {
-    const int tid = threadIdx.x, il = F.images_level, P = F.P;
+    const int tid = threadIdx.x, P = F.P;
 #if FC_VARIANT_BIG
-    pred_save_tables(F, sh, s);         /* residual search: the id may belong to a displaced state */
+    const int il = F.images_level;
 #endif
-    /* term lists of the new state s (slot 0 = tree child with weight 1 if any, then the
-     * edges): twelve lanes read one row slot each (one memory round trip instead of a chain of
-     * dependent ones), two lanes compact them into LDS; uniform for the whole workgroup */
-#if !FC_VARIANT_BIG
-    /* default build: store_new_state() has left the term lists in sh.gs_* */
-#else
-    if (tid < 12) {
-        const int l = tid / 6, e = tid % 6;
-        sh.gs_raw_idx[l][e] = e == 0 ? (int) TREE(F, s, l) : (int) INTO(F, s, l, e - 1);
-        sh.gs_raw_w[l][e] = e == 0 ? 1.0f : WEIGHT(F, s, l, e - 1);
-    }
-    __syncthreads();
-    if (tid < 2) {
-        const int l = tid;
-        int m = 0;
-        sh.gs_c[l] = sh.gs_raw_idx[l][0] != RANGE_;
-        if (sh.gs_c[l]) { sh.gs_idx[l][0] = sh.gs_raw_idx[l][0]; sh.gs_w[l][0] = 1.0f; m = 1; }
-        for (int e = 1; e <= MAXED && sh.gs_raw_idx[l][e] != NOEDGE; e++) {
-            sh.gs_idx[l][m] = sh.gs_raw_idx[l][e]; sh.gs_w[l][m] = sh.gs_raw_w[l][e]; m++;
-        }
-        sh.gs_n[l] = m;
-        for (; m <= MAXED; m++) { sh.gs_idx[l][m] = 0; sh.gs_w[l][m] = 0.0f; }   /* valid dummies */
-    }
-    __syncthreads();
-#endif
-    /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
-     * depends on level l-1 of OTHER states only (codec/control.c:205-258) */
-    GLOBAL_AS float *const gimg = uniform_ptr(F.img);
-    GLOBAL_AS float *const gimgT = uniform_ptr(F.imgT);
-    const int NIu = __builtin_amdgcn_readfirstlane(F.NI);
-    if (tid == B - 1) stg(gimg, (unsigned) (s * NIu), F.final_d[s]);
-    for (int i = tid; i < NIu - 1; i += B) {
-        int l = 31 - __clz(i + 2);                      /* offset 2^l - 1 + pos = i + 1 */
-        int pos = i + 1 - ((1 << l) - 1);
-        const int half = 1 << (l - 1), label = pos >= half;
-        const int off = half - 1 + (pos - label * half);
-        const int n = sh.gs_n[label];
-        float t[FC_MAXE + 1];
-#pragma unroll
-        for (int a = 0; a <= FC_MAXE; a++)              /* all term images in flight */
-            t[a] = ldg((GLOBAL_AS const float *) gimg, (unsigned) (sh.gs_idx[label][a] * NIu + off));      /* dead slots: state 0 */
-        float v = 0;
-#pragma unroll
-        for (int a = 0; a <= FC_MAXE; a++)
-            if (a < n) v = (a == 0 && sh.gs_c[label]) ? t[0] : v + t[a] * sh.gs_w[label][a];
-        stg(gimg, (unsigned) (s * NIu + i + 1), v);
-        if (l == il) stg(gimgT, (unsigned) (pos * P + s), v);
-#if FC_VARIANT_BIG
-        if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) pos * P + s] = v;
-#endif
-    }
-    __syncthreads();
-    /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
     {
         const int flim = __builtin_amdgcn_readfirstlane(sh.flim);
         const int Pu = __builtin_amdgcn_readfirstlane(P);
@@ -1551,7 +1503,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         float vs[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) vs[k] = ldg(imgT, (unsigned) (k * Pu + s));
-        for (int t = tid; t <= s; t += B) {
+        for (int t = tid + part * B; t <= s; t += B * parts) {
             EdgeRows rows;
             load_edge_rows(T, t, rows);
             float vt[32];
@@ -1669,6 +1621,123 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
             }
         }
     }
+}
+
+#if FC_SPEC
+/* ... as a call: the shares of a dealt row (chain and append helpers) */
+__device__ __noinline__ void append_row_part_ool(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s, int part, int parts)
+{
+    append_row_part(F, sh, s, part, parts);
+}
+#endif
+
+/* codec/control.c:48-131 for a non-auxiliary state s whose edges are already stored */
+__device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict__ sh, int s)
+{
+    const int tid = threadIdx.x, il = F.images_level, P = F.P;
+#if FC_VARIANT_BIG
+    pred_save_tables(F, sh, s);         /* residual search: the id may belong to a displaced state */
+#endif
+    /* term lists of the new state s (slot 0 = tree child with weight 1 if any, then the
+     * edges): twelve lanes read one row slot each (one memory round trip instead of a chain of
+     * dependent ones), two lanes compact them into LDS; uniform for the whole workgroup */
+#if !FC_VARIANT_BIG
+    /* default build: store_new_state() has left the term lists in sh.gs_* */
+#else
+    if (tid < 12) {
+        const int l = tid / 6, e = tid % 6;
+        sh.gs_raw_idx[l][e] = e == 0 ? (int) TREE(F, s, l) : (int) INTO(F, s, l, e - 1);
+        sh.gs_raw_w[l][e] = e == 0 ? 1.0f : WEIGHT(F, s, l, e - 1);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const int l = tid;
+        int m = 0;
+        sh.gs_c[l] = sh.gs_raw_idx[l][0] != RANGE_;
+        if (sh.gs_c[l]) { sh.gs_idx[l][0] = sh.gs_raw_idx[l][0]; sh.gs_w[l][0] = 1.0f; m = 1; }
+        for (int e = 1; e <= MAXED && sh.gs_raw_idx[l][e] != NOEDGE; e++) {
+            sh.gs_idx[l][m] = sh.gs_raw_idx[l][e]; sh.gs_w[l][m] = sh.gs_raw_w[l][e]; m++;
+        }
+        sh.gs_n[l] = m;
+        for (; m <= MAXED; m++) { sh.gs_idx[l][m] = 0; sh.gs_w[l][m] = 0.0f; }   /* valid dummies */
+    }
+    __syncthreads();
+#endif
+    /* images: level 0 is the final distribution (control.c:97); a level l >= 1 element
+     * depends on level l-1 of OTHER states only (codec/control.c:205-258) */
+    GLOBAL_AS float *const gimg = uniform_ptr(F.img);
+    GLOBAL_AS float *const gimgT = uniform_ptr(F.imgT);
+    const int NIu = __builtin_amdgcn_readfirstlane(F.NI);
+    if (tid == B - 1) stg(gimg, (unsigned) (s * NIu), F.final_d[s]);
+    for (int i = tid; i < NIu - 1; i += B) {
+        int l = 31 - __clz(i + 2);                      /* offset 2^l - 1 + pos = i + 1 */
+        int pos = i + 1 - ((1 << l) - 1);
+        const int half = 1 << (l - 1), label = pos >= half;
+        const int off = half - 1 + (pos - label * half);
+        const int n = sh.gs_n[label];
+        float t[FC_MAXE + 1];
+#pragma unroll
+        for (int a = 0; a <= FC_MAXE; a++)              /* all term images in flight */
+            t[a] = ldg((GLOBAL_AS const float *) gimg, (unsigned) (sh.gs_idx[label][a] * NIu + off));      /* dead slots: state 0 */
+        float v = 0;
+#pragma unroll
+        for (int a = 0; a <= FC_MAXE; a++)
+            if (a < n) v = (a == 0 && sh.gs_c[label]) ? t[0] : v + t[a] * sh.gs_w[label][a];
+        stg(gimg, (unsigned) (s * NIu + i + 1), v);
+        if (l == il) stg(gimgT, (unsigned) (pos * P + s), v);
+#if FC_VARIANT_BIG
+        if (l == il - 1 && F.gl0 < il) F.imgT4[(size_t) pos * P + s] = v;
+#endif
+    }
+    __syncthreads();
+    /* Gram row/column of s at every table level; level q needs level q-1 of states < s */
+#if FC_SPEC
+    {
+        /* a long row of the chain of a frame with append helpers: dealt (FcSpecCtl.app_*) */
+        FcSpecCtl *const c = sh.sl.ctl;
+        const bool deal = sh.sl.role == 0 && sh.sl.on && c && sh.sl.app_H > 0 && !sh.sl.app_off
+                          && (unsigned) (s + 1) >= sh.sl.app_min;                      /* uniform */
+        if (!deal) append_row_part(F, sh, s, 0, 1);
+        else {
+            const unsigned H = sh.sl.app_H;
+            __threadfence();                    /* images of s, its automaton row: before the row is published */
+            __syncthreads();
+            if (tid == 0) {
+                c->app_s = s; c->app_flim = sh.flim;
+                for (int l = 0; l < 2; l++) {
+                    c->app_n[l] = sh.gs_n[l]; c->app_c[l] = sh.gs_c[l];
+                    for (int e = 0; e <= MAXED; e++) { c->app_idx[l][e] = sh.gs_idx[l][e]; c->app_w[l][e] = sh.gs_w[l][e]; }
+                }
+                __hip_atomic_store(&c->app_seq, ++sh.sl.app_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            append_row_part_ool(F, sh, s, 0, (int) H + 1);
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned want = sh.sl.app_seq * H;
+                const unsigned long long t0 = wall_clock64();
+                int late = 0;
+                while (__hip_atomic_load(&c->app_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if (wall_clock64() - t0 > c->app_wait) { late = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                sh.sl.t_app_wait += wall_clock64() - t0;
+                sh.sl.n_app_dealt++;
+                if (late) {
+                    /* helpers that do not answer (not resident: masked CUs, a busy device).  A helper that turns up
+                     * later could write a row the chain has re-made since: the frame is given up -- FC_ERR_COOP, the
+                     * host searches it again without helpers (core_hip.cpp complete_wave) -- and the helpers are sent home */
+                    sh.sl.app_off = 1;
+                    sh.failed = FC_ERR_COOP;
+                    __hip_atomic_store(&c->app_off, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the helpers' entries, not this CU's stale lines */
+        }
+    }
+#else
+    append_row_part(F, sh, s, 0, 1);
+#endif
     {
         GLOBAL_AS float *const gd5 = uniform_ptr(ACT_D5(F, sh));
         for (int a = tid; a < F.NA; a += B) {
@@ -3707,6 +3776,49 @@ __device__ __noinline__ void spec_worker(DevFrame &__restrict__ F, Sh &__restric
 }
 #endif
 
+#if FC_SPEC
+/* Append helper h of the H helpers of a frame (all lanes; returns when the chain is done): the entries t with
+ * (t / B) mod (H + 1) == h + 1 of every Gram row the chain publishes (FcSpecCtl.app_*, frame_coder.h).  F is the CHAIN's
+ * descriptor, read only; of sh only what append_row_part looks at is set up. */
+__device__ __noinline__ void spec_append_helper(DevFrame &__restrict__ F, Sh &__restrict__ sh, unsigned h, unsigned H)
+{
+    __shared__ int ah_go, ah_s;
+    const int tid = threadIdx.x;
+    FcSpecCtl *const c = F.spec;
+    unsigned seen = 0;
+    if (!c) return;                                  /* the launch speculates without its buffers: nothing to help with */
+    if (tid == 0) { sh.gap_lo = sh.gap_hi = 0; sh.gap_shift = 0; sh.deadmask = 0; sh.band = 0; }
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            int go = 0;
+            for (;;) {
+                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                    || __hip_atomic_load(&c->app_off, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+                const unsigned q = __hip_atomic_load(&c->app_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (q != seen) { seen = q; go = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (go) {
+                ah_s = c->app_s; sh.flim = c->app_flim;
+                for (int l = 0; l < 2; l++) {
+                    sh.gs_n[l] = c->app_n[l]; sh.gs_c[l] = c->app_c[l];
+                    for (int e = 0; e <= MAXED; e++) { sh.gs_idx[l][e] = c->app_idx[l][e]; sh.gs_w[l][e] = c->app_w[l][e]; }
+                }
+            }
+            ah_go = go;
+        }
+        __syncthreads();
+        if (!ah_go) break;                           /* uniform */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the chain's rows, images and automaton: nothing stale */
+        append_row_part_ool(F, sh, ah_s, (int) h + 1, (int) H + 1);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&c->app_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#endif
+
 /* basis states: images, Gram tables (codec/control.c:133-173); lane 0, a few hundred flops */
 __device__ void basis_init(DevFrame &F, Sh &sh)
 {
@@ -3800,7 +3912,7 @@ __global__ void __launch_bounds__(B, FC_WG_PER_CU)
 /* G workgroups per frame: workgroup f * G is the chain of frame f (descriptor frames[f]), the G - 1
  * after it are its verifiers (descriptors vframes[f * (G - 1) ..]: the chain's with private
  * <sub-block, state> tables, scratch and state-id range).  G == 1: no speculation. */
-FC_KERNEL(DevFrame *frames, DevFrame *vframes, unsigned G)
+FC_KERNEL(DevFrame *frames, DevFrame *vframes, unsigned G, unsigned n, unsigned H)
 #else
 FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *ctr, const unsigned *ptrmask,
           unsigned long long queue_wait_ticks, unsigned coopW)
@@ -3820,6 +3932,12 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
     __shared__ unsigned task_seq, spec_slot, spec_used, spec_vid;
     __shared__ int task_go, spec_act, spec_bad;
     if (threadIdx.x == 0) spec_bad = 0;
+    if (blockIdx.x >= n * G) {
+        /* behind the n * G workgroups of the frames: H append helpers per frame, on the chain's descriptor (read only) */
+        const unsigned k = blockIdx.x - n * G;
+        spec_append_helper(frames[k / H], sh, k % H, H);
+        return;
+    }
     const unsigned role = blockIdx.x % G;
     DevFrame &F = role ? vframes[(blockIdx.x / G) * (G - 1) + role - 1] : frames[blockIdx.x / G];
     unsigned long long *const ring = nullptr;
@@ -3904,6 +4022,8 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sl.T = F.spec_T; sl.tabs = F.spec ? (char *) F.spec + F.spec->off_tabs : nullptr;
         sl.chroma_tabs = 0;
         sl.n_tab_used = sl.n_tab_missed = sl.n_adopted = 0;
+        sl.app_H = role == 0 && F.spec && G > 1 ? F.spec->app_H : 0u; sl.app_min = F.spec ? F.spec->app_min : 0u;
+        sl.app_seq = 0; sl.app_off = 0; sl.n_app_dealt = sl.t_app_wait = 0;
         for (int k = 0; k < 32; k++) sl.rb_s[k] = 0;
         sh.blk = 0; sh.tab_shared = 0; sh.tab_from = 0;
         sl.floor = 0; sl.head = sl.commit = 0; sl.spec_mask = 0; sl.nospec = 0; sl.epoch = 0;
@@ -4517,6 +4637,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         c->n_tasks = sh.sl.n_tasks; c->n_confirmed = sh.sl.n_confirmed; c->n_wrong = sh.sl.n_wrong;
         c->n_timeout = sh.sl.n_timeout; c->n_inline = sh.sl.n_inline; c->t_wait = sh.sl.t_wait;
         c->n_tab_used = sh.sl.n_tab_used; c->n_tab_missed = sh.sl.n_tab_missed; c->n_adopted = sh.sl.n_adopted;
+        c->n_app_dealt = sh.sl.n_app_dealt; c->t_app_wait = sh.sl.t_app_wait;
     }
 #endif
     if (tid == 0) {
@@ -4597,9 +4718,10 @@ extern "C" int FC_OCCUPANCY(void)
 #if FC_SPEC
 /* n frames, G workgroups each (all n * G must be resident at once: a chain whose verifiers are not
  * does their blocks itself after a bounded wait, see spec_poll) */
-extern "C" void FC_LAUNCH(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, hipStream_t stream)
+extern "C" void FC_LAUNCH(DevFrame *d_frames, DevFrame *d_vframes, unsigned n, unsigned G, unsigned H, hipStream_t stream)
 {
-    hipLaunchKernelGGL(FC_KERNEL, dim3(n * G), dim3(B), 0, stream, d_frames, d_vframes, G);
+    /* ... and H append helpers per frame behind them (FcSpecCtl.app_H of every frame of the launch; 0: none) */
+    hipLaunchKernelGGL(FC_KERNEL, dim3(n * (G + H)), dim3(B), 0, stream, d_frames, d_vframes, G, n, H);
 }
 extern "C" unsigned FC_SPEC_SLOT_BYTES(void) { return SPEC_STRIDE; }
 #if !FC_VARIANT_WIDE

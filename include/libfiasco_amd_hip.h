@@ -52,6 +52,9 @@ typedef struct fiasco_amd_stats {
     unsigned long long decoder_frames, decoder_bytes, decoder_us;
     /* big frames whose table passes were built by several workgroups (frame_coder.h FcCoop), and how many each */
     unsigned long long coop_frames, coop_workgroups;
+    /* speculating frames with append helpers (frame_coder.h FcSpecCtl.app_*): Gram rows of appended states that were
+     * dealt to the helpers, ticks (100 MHz) the chains waited for them */
+    unsigned long long spec_app_rows, spec_app_wait;
 } fiasco_amd_stats;
 
 void fiasco_amd_get_stats(fiasco_amd_stats *out);
@@ -98,6 +101,11 @@ int fiasco_amd_rccl_gather(void *comm, void *stream, int rank, int world, int ro
 /* workgroups per frame the launcher gives the table passes of `frames` big frames (prediction, P/B frames, -z 1/2)
  * on a chip of `cus` CUs: 1, 2, 4 or 8 (csrc/hip/frame_coder.h FcCoop); pure function */
 unsigned fiasco_amd_coop_workgroups(unsigned frames, int cus);
+/* append helpers per frame the launcher adds to a launch of `frames` speculating frames with G workgroups each
+ * (wide_build: the 1024-thread build, frames beyond 3072 states): workgroups that build their shares of the Gram row of
+ * every state the chain appends (codec/control.c:48-131, codec/ip.c:184-260; csrc/hip/frame_coder.h FcSpecCtl.app_*).
+ * A pure function of its arguments (no device). */
+int fiasco_amd_spec_append_helpers(unsigned frames, int cus, int G, int wide_build);
 /* which of `shares` device shares of the process takes a job (a pure function, no device): share_key == 0 -> the job's
  * index in the call, round robin (frames of a batch); share_key = key + 1 -> key mod shares whatever the
  * index and however many jobs the call holds.  The sequence engine keys the frames of a video and the decodes of their

@@ -26,9 +26,10 @@ for mode in modes:
     b = fiasco_amd.Batch(lib, frames, 20.0, opt)
     for rep in range(2):
         lib.reset_stats(); out = b.encode(); st = lib.get_stats()
-    print("%dx%d n=%d mode=%s: kernel %.3f s %.1f frames/s | spec frames %d tasks %d wrong %d (taken over %d) inline %d wait %.2f s tables %d/%d"
+    print("%dx%d n=%d mode=%s: kernel %.3f s %.1f frames/s | spec frames %d tasks %d wrong %d (taken over %d) inline %d wait %.2f s tables %d/%d | append rows dealt %d, wait %.3f s (FIASCO_AMD_SPEC_APP=%s)"
           % (w, h, n, mode, st.kernel_ms / 1e3, n / (st.kernel_ms / 1e3), st.spec_frames, st.spec_tasks, st.spec_wrong, st.spec_adopted,
-             st.spec_inline, st.spec_wait / 1e8, st.spec_tab_used, st.spec_tab_missed), flush=True)
+             st.spec_inline, st.spec_wait / 1e8, st.spec_tab_used, st.spec_tab_missed, st.spec_app_rows, st.spec_app_wait / 1e8,
+             os.environ.get("FIASCO_AMD_SPEC_APP", "auto")), flush=True)
     if any(o is None for o in out): print("   ERROR", lib.error_message())
     if ref is None: ref = out
     else: print("   identical" if out == ref else "   MISMATCH")

@@ -29,8 +29,8 @@ pytestmark = pytest.mark.gpu
 REF = os.path.join(ROOT, "oracle", "_ref", "cfiasco_ref")
 CLI_OBJS = [os.path.join(ROOT, "oracle", "_ref", "obj", "bin_%s.o" % n)
             for n in ("cwfa", "params", "binerror", "getopt", "getopt1")]
-N_CASES = 40
-SEED0 = 60600
+N_CASES = int(os.environ.get("FUZZ_REF_CASES", "40"))        # long runs of the round: FUZZ_REF_CASES=300 FUZZ_REF_SEED=...
+SEED0 = int(os.environ.get("FUZZ_REF_SEED", "60600"))
 
 
 @pytest.fixture(scope="module")
@@ -123,5 +123,11 @@ def test_device_equals_the_real_reference_on_random_cases(product_cli, tmp_path)
                         None if want is None else hashlib.md5(want).hexdigest(),
                         None if got is None else hashlib.md5(got).hexdigest(), p.stderr[-300:]))
     print("device vs REAL reference: %d cases from seed %d: %s" % (N_CASES, SEED0, tally))
-    assert not bad, bad
+    if bad:                                             # the whole story, not pytest's shortened repr
+        import json
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(bad, open(os.path.join(ROOT, "gpurun_out", "fuzz_reference_failures.json"), "w"), indent=1)
+        for b in bad:
+            print("MISMATCH seed %d %s: %s\n   reference rc %d md5 %s, device rc %d md5 %s: %s" % (b[0], b[1], b[2], b[3], b[5], b[4], b[6], b[7]))
+    assert not bad, [b[0] for b in bad]
     assert tally["ok"] >= N_CASES * 3 // 4, tally          # the comparison must not be hollow

@@ -1893,6 +1893,7 @@ static bool launch_wave(Staged *S)
                     const int wk = i < group_n[7] ? 0 : 1;
                     h.app_H = (unsigned) S->specH[wk];
                     h.app_min = wk ? 2048u : 512u;               /* two passes of the workgroup's lanes */
+                    h.app_dbg = fa_knob("FIASCO_AMD_SPEC_APPDBG") ? (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPDBG")) : 0u;
                     h.app_wait = fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS") ? 100000u * (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS")) : 200000000u;   /* 2 s */
                 }
                 fail = hipMemcpy(S->d_spec + span * i, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess;

@@ -323,6 +323,7 @@ typedef struct FcSpecCtl {
     unsigned app_seq;               /* rows published by the chain */
     unsigned app_done;              /* arrivals of the helpers (cumulative) */
     unsigned app_off;               /* the chain has given up: helpers go home */
+    unsigned app_dbg;               /* developer (FIASCO_AMD_SPEC_APPDBG): 1 helpers answer without building, 2 the chain builds every share again after them (host) */
     int      app_s, app_flim;       /* the row: state id; sh.flim of the chain */
     int      app_n[2], app_c[2], app_idx[2][FC_MAXED + 1];      /* Sh::gs_n, gs_c, gs_idx, gs_w of the new state */
     float    app_w[2][FC_MAXED + 1];

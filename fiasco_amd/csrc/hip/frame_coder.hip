@@ -587,6 +587,29 @@ __device__ __forceinline__ void stg(GLOBAL_AS T *base, unsigned i, T v)
     *(GLOBAL_AS T *) ((GLOBAL_AS char *) base + i * (unsigned) sizeof(T)) = v;
 }
 
+/* ------------------------------------------------------------------ hand-offs between workgroups
+ *
+ * Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores
+ * (MI355X_MICROARCH.md, "inter-workgroup visibility"): data for another workgroup is PUBLISHED -- every wave drains its
+ * stores, the workgroup meets, ONE lane writes the XCD L2's dirty lines back (agent-scope release) and only then stores
+ * the flag -- and TAKEN by polling the flag relaxed, ONE agent-scope acquire (drops this CU's L1) and a barrier before
+ * the plain loads.  The explicit waits are not decoration: ROCm 7.2 drops the `s_waitcnt vmcnt(0)' behind `buffer_wbl2'
+ * whenever its scoreboard says the publishing wave has nothing outstanding, and the flag then overtakes the write-back
+ * (round 6: the append helpers read the PREVIOUS row's descriptor until the wait was written out). */
+#define WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+/* lane 0 of a workgroup whose waves have all drained and met (WAVE_DRAIN(); __syncthreads();): after this a relaxed
+ * agent-scope store / fetch_add of the flag publishes everything the workgroup has written */
+__device__ __forceinline__ void publish_release(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+/* the taker's side, one lane, after it has seen the flag (relaxed): nothing stale of the publisher's data in this CU's L1 */
+__device__ __forceinline__ void take_acquire(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 /* ------------------------------------------------------------------ table access */
 
 /* Gram tables, two layouts (frame_coder.h): full symmetric P x P per level, or -- FC_GRAM_TRI,
@@ -1700,7 +1723,7 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
         if (!deal) append_row_part(F, sh, s, 0, 1);
         else {
             const unsigned H = sh.sl.app_H;
-            __threadfence();                    /* images of s, its automaton row: before the row is published */
+            WAVE_DRAIN();                       /* images of s, its automaton row: in L2 before the row is published */
             __syncthreads();
             if (tid == 0) {
                 c->app_s = s; c->app_flim = sh.flim;
@@ -1708,18 +1731,21 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                     c->app_n[l] = sh.gs_n[l]; c->app_c[l] = sh.gs_c[l];
                     for (int e = 0; e <= MAXED; e++) { c->app_idx[l][e] = sh.gs_idx[l][e]; c->app_w[l][e] = sh.gs_w[l][e]; }
                 }
-                __hip_atomic_store(&c->app_seq, ++sh.sl.app_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                publish_release();
+                __hip_atomic_store(&c->app_seq, ++sh.sl.app_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             append_row_part_ool(F, sh, s, 0, (int) H + 1);
             __syncthreads();
             if (tid == 0) {
                 const unsigned want = sh.sl.app_seq * H;
+                const unsigned wait_ticks = c->app_wait;
                 const unsigned long long t0 = wall_clock64();
                 int late = 0;
-                while (__hip_atomic_load(&c->app_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    if (wall_clock64() - t0 > c->app_wait) { late = 1; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                while (__hip_atomic_load(&c->app_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if (wall_clock64() - t0 > wait_ticks) { late = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                take_acquire();                 /* the helpers' entries, not this CU's stale lines */
                 sh.sl.t_app_wait += wall_clock64() - t0;
                 sh.sl.n_app_dealt++;
                 if (late) {
@@ -1728,11 +1754,12 @@ __device__ __noinline__ void op_append(DevFrame &__restrict__ F, Sh &__restrict_
                      * host searches it again without helpers (core_hip.cpp complete_wave) -- and the helpers are sent home */
                     sh.sl.app_off = 1;
                     sh.failed = FC_ERR_COOP;
-                    __hip_atomic_store(&c->app_off, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->app_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the helpers' entries, not this CU's stale lines */
+            if (c->app_dbg)                     /* developer: the helpers' shares once more, here */
+                for (int p = 1; p <= (int) H; p++) append_row_part_ool(F, sh, s, p, (int) H + 1);
         }
     }
 #else
@@ -3762,13 +3789,15 @@ __device__ __noinline__ void spec_worker(DevFrame &__restrict__ F, Sh &__restric
         if (!tw_go) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         op_init_range(F, sh, tw_x, tw_y, 0);
-        __threadfence();
+        WAVE_DRAIN();
         __syncthreads();
         if (tid == 0) {
             const unsigned b = j % FC_SPEC_R;
+            publish_release();
             __hip_atomic_store(&c->tab_s[b], (unsigned) sh.states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->tab_epoch[b], tw_e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&c->tab_seq[b], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            WAVE_DRAIN();                       /* tab_s / tab_epoch before tab_seq */
+            __hip_atomic_store(&c->tab_seq[b], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dynamic) j = c->n_tabs + 1;     /* take the next one */
             else j += T;
         }
@@ -3792,14 +3821,15 @@ __device__ __noinline__ void spec_append_helper(DevFrame &__restrict__ F, Sh &__
         __syncthreads();
         if (tid == 0) {
             int go = 0;
-            for (;;) {
-                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-                    || __hip_atomic_load(&c->app_off, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
-                const unsigned q = __hip_atomic_load(&c->app_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {                               /* relaxed polls, ONE acquire once there is something to take */
+                if (__hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    || __hip_atomic_load(&c->app_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                const unsigned q = __hip_atomic_load(&c->app_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (q != seen) { seen = q; go = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
             if (go) {
+                take_acquire();                      /* the chain's rows, images, automaton and the descriptor: nothing stale */
                 ah_s = c->app_s; sh.flim = c->app_flim;
                 for (int l = 0; l < 2; l++) {
                     sh.gs_n[l] = c->app_n[l]; sh.gs_c[l] = c->app_c[l];
@@ -3810,11 +3840,11 @@ __device__ __noinline__ void spec_append_helper(DevFrame &__restrict__ F, Sh &__
         }
         __syncthreads();
         if (!ah_go) break;                           /* uniform */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the chain's rows, images and automaton: nothing stale */
-        append_row_part_ool(F, sh, ah_s, (int) h + 1, (int) H + 1);
-        __threadfence();
+        if (c->app_dbg != 1) append_row_part_ool(F, sh, ah_s, (int) h + 1, (int) H + 1);
+        WAVE_DRAIN();
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&c->app_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) publish_release();
+        if (tid == 0) __hip_atomic_fetch_add(&c->app_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 #endif
@@ -4386,17 +4416,21 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
             __syncthreads();
             if (spec_act == 1) {
                 const unsigned seq = sh.sl.head, slot = seq % FC_SPEC_W;
+                /* (hand-off recipe at the top of the file: the waves drain, ONE lane releases -- this runs once per block
+                 * of the largest level, 8 100 times per 4K frame; until round 6 every lane fenced twice here.)  The slot is
+                 * marked "being written" with a write-through store that is complete before any of its new bytes exist */
                 if (tid == 0) __hip_atomic_store(&c->slot_seq[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
+                WAVE_DRAIN();
                 __syncthreads();
                 uint4 *dst = (uint4 *) (sh.sl.slots + (size_t) slot * SPEC_STRIDE);
                 for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) dst[i] = ((const uint4 *) &sh)[i];
-                __threadfence();                 /* + every table row written so far */
+                WAVE_DRAIN();                    /* the slot + every table row written so far: in L2 */
                 __syncthreads();
                 if (tid == 0) {
                     /* every table row of the states so far is complete and visible: table workers may use them */
-                    __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    publish_release();
+                    __hip_atomic_store(&c->s_pub, (unsigned) sh.states, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->slot_seq[slot], seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sh.sl.head = seq + 1; sh.sl.spec_mask &= ~(1u << slot); sh.sl.n_tasks++;
                     sh.sl.blkof[slot] = (unsigned) (sh.blk - 1);
                     sh.sl.sk[slot] = (unsigned) sh.states;

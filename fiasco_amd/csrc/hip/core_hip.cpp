@@ -859,7 +859,7 @@ static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only
  * shares of every Gram row the chain appends.  For the 1024-thread speculating build (frames beyond 3072 states: 4K),
  * whose launches give a frame a CU per workgroup and leave the rest of the chip empty -- BASELINE config 4 as written
  * puts 8 frames on a GPU: 8 x 8 workgroups on 256 CUs -- and whose rows are long (up to 10 passes of the 1024 lanes).
- * As many as the chip has CUs left for, at most 7; fewer than 2 are not worth the hand-off.  A function of its arguments
+ * Three where the chip has CUs left for them; fewer than 2 are not worth the hand-off.  A function of its arguments
  * alone (fiasco_amd_spec_append_helpers); FIASCO_AMD_SPEC_APP=<H> (tests, experiments) asks for H, also in the
  * 256-thread build. */
 static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int occ)
@@ -871,11 +871,10 @@ static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int o
     const char *e = fa_knob("FIASCO_AMD_SPEC_APP");
     if (e) { const size_t want = (size_t) (atoi(e) > 0 ? atoi(e) : 0); return (int) (want < H ? want : H); }
     if (!wide_build) return 0;
-    /* 4K frames slow each other down once more than half the CUs work on them (spec_policy): the helpers stay inside
-     * that half */
-    const size_t half = (size_t) cus / (2 * frames);
-    H = half > (size_t) G ? half - (size_t) G : 0;
-    if (H > 7) H = 7;
+    /* measured (8 x 4K, round 6): 2, 3, 5 and 7 helpers give the same 1.58 .. 1.62 s against 1.87 without -- the hand-off
+     * (two releases, two acquires per row) is what a dealt row costs, not the shares; 16 frames 8.5 -> 9.6 frames/s with 3
+     * (helpers are light: they may use the half of the chip the frames' own workgroups leave alone, spec_policy) */
+    if (H > 3) H = 3;
     return H >= 2 ? (int) H : 0;
 }
 extern "C" int fiasco_amd_spec_append_helpers(unsigned frames, int cus, int G, int wide_build)
@@ -922,10 +921,10 @@ static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only
         else if (2 * 4 * frames <= 3 * (size_t) cus) G = 4;        /* 1.5 */
         else if (frames <= (size_t) cus) G = 3;                    /* 3 */
     }
-    /* 4K frames (the 1024-thread build; tables of megabytes per block): more than half the CUs busy
-     * with them and they slow each other down -- 32 frames: 7.2 frames/s with 8 workgroups each, 7.9
-     * with 6, 9.1 with 4 */
-    if (big_frames && G > 4 && 2 * frames * G > (size_t) cus) G = (size_t) cus / (2 * frames) >= 4 ? (size_t) cus / (2 * frames) : 4;
+    /* (Until round 5 4K frames were kept to half the CUs -- 32 frames: 7.2 frames/s with 8 workgroups each, 9.1 with 4:
+     * every lane of every workgroup fenced at each hand-off and the L2 write-backs slowed everybody down.  With one
+     * releasing lane per hand-off, round 6: 32 frames 10.6 with 4, 15.2 with 6, 15.4 with 8; 24 frames 9.4 -> 13.4.) */
+    (void) big_frames;
     return G >= 3 ? (int) G : 0;
 }
 
@@ -1893,6 +1892,7 @@ static bool launch_wave(Staged *S)
                     const int wk = i < group_n[7] ? 0 : 1;
                     h.app_H = (unsigned) S->specH[wk];
                     h.app_min = wk ? 2048u : 512u;               /* two passes of the workgroup's lanes */
+                    if (fa_knob("FIASCO_AMD_SPEC_APPMIN")) h.app_min = (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPMIN"));
                     h.app_dbg = fa_knob("FIASCO_AMD_SPEC_APPDBG") ? (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPDBG")) : 0u;
                     h.app_wait = fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS") ? 100000u * (unsigned) atoi(fa_knob("FIASCO_AMD_SPEC_APPWAIT_MS")) : 200000000u;   /* 2 s */
                 }

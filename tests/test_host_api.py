@@ -33,7 +33,7 @@ def test_headers_and_symbol_list_agree():
 def test_workgroups_per_frame_of_a_launch(product):
     """The launcher's policy for small launches (a pure function, no device): a CU per
     workgroup down to five per frame, then shared CUs -- 256-thread build only -- down to three per frame
-    and three per CU; 4K frames never share a CU and leave half the chip alone."""
+    and three per CU; 4K frames never share a CU."""
     f = product.L.fiasco_amd_spec_workgroups
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -43,8 +43,14 @@ def test_workgroups_per_frame_of_a_launch(product):
     # frames that may need the 1024-thread build, or a build a CU holds only one of: a CU per workgroup
     assert [f(n, 256, 0, 0, 5) for n in (51, 64, 85, 86)] == [5, 4, 3, 0]
     assert [f(n, 256, 0, 1, 1) for n in (64, 85, 86)] == [4, 3, 0]
-    # 4K: at most half the CUs once a frame has four workgroups
-    assert [f(n, 256, 1, 0, 1) for n in (1, 8, 16, 32, 64, 85, 86)] == [8, 8, 8, 4, 4, 3, 0]
+    # 4K: a CU per workgroup, like the others (until round 5: at most half the CUs once a frame had four)
+    assert [f(n, 256, 1, 0, 1) for n in (1, 8, 16, 32, 33, 48, 64, 85, 86)] == [8, 8, 8, 8, 7, 5, 4, 3, 0]
+    # ... and append helpers for the chains where CUs are left (fiasco_amd_spec_append_helpers: frames, CUs, G, wide build)
+    h = product.L.fiasco_amd_spec_append_helpers
+    h.restype = ctypes.c_int
+    h.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    assert [h(n, 256, 8, 1) for n in (1, 8, 16, 23, 24, 25, 26, 32)] == [3, 3, 3, 3, 2, 2, 0, 0]
+    assert h(8, 256, 8, 0) == 0 and h(0, 256, 8, 1) == 0 and h(8, 256, 1, 1) == 0
     assert f(0, 256, 0, 1, 5) == 0 and f(4, 0, 0, 1, 5) == 0
 
 

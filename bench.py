@@ -229,6 +229,22 @@ def k4_pass(lib, nframes, rank):
             "limits": "MAXSTATES 30000, MAXLEVEL 26 (declared extension, SURVEY 8c)"}
 
 
+def launch_form(lib, frames, w, h, cus=256):
+    """The launcher's choice for a launch of `frames` gray frames of w x h on one GPU (pure policy functions of the
+    library, include/libfiasco_amd_hip.h): kernel build, workgroups per frame, append helpers per frame."""
+    big = 1 if max(w, h) > 2048 else 0
+    g = int(lib.L.fiasco_amd_spec_workgroups(frames, cus, big, 0 if big else 1, 1 if big else 5))
+    if g:
+        build = "fiasco_frame_kernel_spec_wide (1024 threads)" if big else "fiasco_frame_kernel_spec (256 threads)"
+        return {"frames": frames, "kernel_build": build, "workgroups_per_frame": g,
+                "append_helpers_per_frame": int(lib.L.fiasco_amd_spec_append_helpers(frames, cus, g, big))}
+    if big:
+        build = "fiasco_frame_kernel_wide_tri (1024 threads, triangular Gram tables, frame queue)"
+    else:
+        build = "fiasco_frame_kernel (256 threads, 4 frames per CU)" if frames > cus else "fiasco_frame_kernel_wide (1024 threads)"
+    return {"frames": frames, "kernel_build": build, "workgroups_per_frame": 1, "append_helpers_per_frame": 0}
+
+
 def k4_small_pass(lib, counts=(64, 8)):
     """BASELINE config 4 as written -- 64 independent 3840x2160 frames -- on ONE GPU, and 8 frames: one GPU's share of
     the job on an 8-GPU node.  Launches this small leave the chip empty: the launcher gives every frame several
@@ -265,6 +281,9 @@ def k4_small_pass(lib, counts=(64, 8)):
                 "kernel_seconds": st.kernel_ms / 1e3, "launches": int(st.launches),
                 "frames_with_several_workgroups": int(st.spec_frames),
                 "workgroups_per_frame": int(lib.L.fiasco_amd_spec_workgroups(n, cus, 1, 0, 1)) or 1,
+                # round 6: further workgroups of a frame that build their shares of the Gram row of every appended state
+                "append_helpers_per_frame": int(lib.L.fiasco_amd_spec_append_helpers(n, cus, int(lib.L.fiasco_amd_spec_workgroups(n, cus, 1, 0, 1)), 1)),
+                "append_rows_dealt": int(st.spec_app_rows),
                 "kernel_build": "fiasco_frame_kernel_spec_wide" if st.spec_frames else "fiasco_frame_kernel_wide / _wide_tri",
                 "frames_by_kernel_build": list(st.frames_by_build),
                 "parity": ("frame 0 == patched reference (%s)" % md5[:12]) if md5 == REF_MD5_SEED1234[(w, h)] else "MISMATCH: %s" % md5}
@@ -656,6 +675,9 @@ def main():
                                    + ("" if a.scaling == "weak" else "; strong scaling: %d frames in all, dealt round robin "
                                                                       "to %d ranks" % (total_job, world)),
                        "frames_per_gpu": F, "distinct_frames_per_gpu": ndist, "frames_total_per_step": total_job,
+                       # what a rank's launch looks like (the SCALE record of a strong-scaling run is read with this):
+                       # kernel build, workgroups per frame, append helpers -- the launcher's policy for F frames on this GPU
+                       "launch_form_per_rank": launch_form(lib, F, a.width, a.height) if not dry else None,
                        "parallelism": "frames x%d" % world,
                        "kernel_only_frames_per_s": nframes / (kernel_ms / 1e3) * world if kernel_ms else None,
                        # raw PNM in host memory -> parse -> pinned -> HBM inside the timed region,

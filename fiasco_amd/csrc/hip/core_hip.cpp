@@ -669,10 +669,15 @@ static Layout make_layout(int P, int PA, int NL, int NS, int NA, int NI, int il,
 static int device_supported(const fa_job *job, char *why, size_t n)
 {
     const fa_cparams *cp = &job->cp;
-    if (job->frame_type != FA_I_FRAME
+    /* a P / B frame whose reference frame is missing (e.g. an I frame coded between a B frame and its past reference:
+     * the reference coder drops both references at an I frame, codec/coder.c:580-628, and dereferences a null frame at
+     * its first motion search) -- IF a motion search can happen: the searches run on ranges of the prediction window
+     * (codec/prediction.c:96-208), and a minimum block level that a colour frame has ratcheted above the window's top
+     * (codec/coder.c:785-797) leaves no such range.  The reference then codes the frame without ever looking at the
+     * missing frame, and so does the device (tests/test_gpu_fuzz_reference.py, seed 71136: pattern `ipb', 4 frames). */
+    const bool window_reachable = (int) cp->p_max_level >= (int) cp->lc_min_level;
+    if (job->frame_type != FA_I_FRAME && window_reachable
         && (!job->past || (job->frame_type == FA_B_FRAME && !job->future) || cp->search_range != 16)) {
-        /* e.g. an I frame as the future reference of B frames: the reference coder dereferences
-         * a null frame at its first motion search */
         snprintf(why, n, "Motion search without a reference frame (frame pattern).");
         return 0;
     }

@@ -3752,14 +3752,14 @@ __device__ __noinline__ void spec_worker(DevFrame &__restrict__ F, Sh &__restric
             const unsigned nb = c->n_blocks;
             bool have = false;                  /* dynamic: j is a block taken from tab_next */
             for (;;) {
-                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                if (__hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
                 if (!dynamic) {
                     const unsigned cur = __hip_atomic_load(&c->blk_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     while (j + 1 < cur) j += T;           /* the chain is past these (it may still wait for block cur - 1) */
                     if (j >= nb) dynamic = true;
                 }
                 if (dynamic) {
-                    if (!__hip_atomic_load(&c->chroma_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) || c->n_tabs <= nb) {
+                    if (!__hip_atomic_load(&c->chroma_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || c->n_tabs <= nb) {
                         __builtin_amdgcn_s_sleep(64);
                         continue;
                     }
@@ -4292,28 +4292,26 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         if (tid == 0) {
             unsigned t = atomicAdd(&c->next, 1u);
             int go = 1;
-            for (;;) {
-                const unsigned q = __hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (q == t + 1) break;
+            for (;;) {                  /* relaxed polls (an acquire per look drops the CU's L1 every time), ONE acquire on a find */
+                const unsigned q = __hip_atomic_load(&c->slot_seq[t % FC_SPEC_W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q == t + 1) { take_acquire(); break; }        /* nothing stale in this CU's L1: the slot, the rows of the states */
                 /* the slot already holds a LATER block: the chain went back behind block t, dropped it and has
                  * come round to the slot again before anybody looked at it.  Waiting for it would be for ever. */
                 if (q > t + 1) { t = atomicAdd(&c->next, 1u); continue; }
-                if (__hip_atomic_load(&c->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
+                if (__hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { go = 0; break; }
                 /* colour frame, luminance band done: nothing left to verify, the chroma bands' tables to build */
-                if (__hip_atomic_load(&c->chroma_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { go = 2; break; }
+                if (__hip_atomic_load(&c->chroma_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { take_acquire(); go = 2; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
             task_seq = t; task_go = go;
         }
         __syncthreads();
         if (task_go != 1) break;                                  /* uniform */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        /* nothing stale in this CU's L1 */
         {   /* the chain's LDS state at the entry of the block */
             const uint4 *src = (const uint4 *) (SPEC_SLOTS(c) + (size_t) (task_seq % FC_SPEC_W) * SPEC_STRIDE);
             for (unsigned i = tid; i < sizeof(Sh) / 16; i += B) ((uint4 *) &sh)[i] = src[i];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
+        __syncthreads();                /* the copy is complete (its loads were waited for by the LDS stores) before lane 0 looks at the slot again */
         if (tid == 0) {
             const unsigned task_epoch = sh.sl.epoch;              /* the chain's, as of the checkpoint */
             /* the slot was not taken for a later block while it was read, and the chain has not gone

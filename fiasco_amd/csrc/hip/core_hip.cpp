@@ -865,8 +865,7 @@ static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only
  * whose launches give a frame a CU per workgroup and leave the rest of the chip empty -- BASELINE config 4 as written
  * puts 8 frames on a GPU: 8 x 8 workgroups on 256 CUs -- and whose rows are long (up to 10 passes of the 1024 lanes).
  * Three where the chip has CUs left for them; fewer than 2 are not worth the hand-off.  A function of its arguments
- * alone (fiasco_amd_spec_append_helpers); FIASCO_AMD_SPEC_APP=<H> (tests, experiments) asks for H, also in the
- * 256-thread build. */
+ * alone (fiasco_amd_spec_append_helpers); FIASCO_AMD_SPEC_APP=<H> (tests, experiments) asks for H. */
 static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int occ)
 {
     if (!frames || G < 2 || cus < 1) return 0;
@@ -875,7 +874,12 @@ static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int o
     size_t H = room > (size_t) G ? room - (size_t) G : 0;
     const char *e = fa_knob("FIASCO_AMD_SPEC_APP");
     if (e) { const size_t want = (size_t) (atoi(e) > 0 ? atoi(e) : 0); return (int) (want < H ? want : H); }
-    if (!wide_build) return 0;
+    if (!wide_build) {
+        /* the 256-thread build (rows of up to 3072 entries, 12 passes of the lanes): three helpers while the launch
+         * stays below 1.5 workgroups per CU -- 1080p: 1 frame 0.367 -> 0.343 s, 16 frames 39.4 -> 42.7, 32 frames 75 -> 80
+         * frames/s; 64 and 128 frames (CUs shared by three and more workgroups): nothing, not given */
+        return H >= 3 && 2 * frames * ((size_t) G + 3) <= 3 * (size_t) cus ? 3 : 0;
+    }
     /* measured (8 x 4K, round 6): 2, 3, 5 and 7 helpers give the same 1.58 .. 1.62 s against 1.87 without -- the hand-off
      * (two releases, two acquires per row) is what a dealt row costs, not the shares; 16 frames 8.5 -> 9.6 frames/s with 3
      * (helpers are light: they may use the half of the chip the frames' own workgroups leave alone, spec_policy) */
@@ -884,7 +888,7 @@ static int spec_app_policy(size_t frames, int cus, int G, bool wide_build, int o
 }
 extern "C" int fiasco_amd_spec_append_helpers(unsigned frames, int cus, int G, int wide_build)
 {
-    return spec_app_policy(frames, cus, G, wide_build != 0, 1);
+    return spec_app_policy(frames, cus, G, wide_build != 0, wide_build ? 1 : 4);      /* the builds' workgroups per CU */
 }
 
 static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only)

@@ -50,7 +50,9 @@ def test_workgroups_per_frame_of_a_launch(product):
     h.restype = ctypes.c_int
     h.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     assert [h(n, 256, 8, 1) for n in (1, 8, 16, 23, 24, 25, 26, 32)] == [3, 3, 3, 3, 2, 2, 0, 0]
-    assert h(8, 256, 8, 0) == 0 and h(0, 256, 8, 1) == 0 and h(8, 256, 1, 1) == 0
+    assert h(0, 256, 8, 1) == 0 and h(8, 256, 1, 1) == 0
+    # the 256-thread build: three while the launch stays below 1.5 workgroups per CU
+    assert [h(n, 256, g, 0) for n, g in ((1, 8), (16, 8), (32, 8), (34, 7), (35, 7), (64, 5), (128, 3))] == [3, 3, 3, 3, 3, 0, 0]
     assert f(0, 256, 0, 1, 5) == 0 and f(4, 0, 0, 1, 5) == 0
 
 

@@ -31,6 +31,10 @@ CLI_OBJS = [os.path.join(ROOT, "oracle", "_ref", "obj", "bin_%s.o" % n)
             for n in ("cwfa", "params", "binerror", "getopt", "getopt1")]
 N_CASES = int(os.environ.get("FUZZ_REF_CASES", "40"))        # long runs of the round: FUZZ_REF_CASES=300 FUZZ_REF_SEED=...
 SEED0 = int(os.environ.get("FUZZ_REF_SEED", "60600"))
+# seeds of the long runs of round 6 (2 x 400 cases, seeds 71000.. and 82000..) on which the device differed from the
+# reference -- both times a REFUSAL where the reference codes the stream (an unsigned prediction-window check; a missing
+# reference frame that no motion search can reach): always run
+PINNED_SEEDS = [71064, 71136]
 
 
 @pytest.fixture(scope="module")
@@ -107,7 +111,7 @@ def test_device_equals_the_real_reference_on_random_cases(product_cli, tmp_path)
     td = str(tmp_path)
     tally = {"ok": 0, "bothfail": 0, "refcrash": 0}
     bad = []
-    for seed in range(SEED0, SEED0 + N_CASES):
+    for seed in list(range(SEED0, SEED0 + N_CASES)) + PINNED_SEEDS:
         args, names, shape = make_case(seed, td)
         r, want = run(REF, args, names, os.path.join(td, "r%d.fco" % seed), env)
         if r.returncode < 0 or r.returncode >= 128:
@@ -122,7 +126,7 @@ def test_device_equals_the_real_reference_on_random_cases(product_cli, tmp_path)
             bad.append((seed, shape, " ".join(args), r.returncode, p.returncode,
                         None if want is None else hashlib.md5(want).hexdigest(),
                         None if got is None else hashlib.md5(got).hexdigest(), p.stderr[-300:]))
-    print("device vs REAL reference: %d cases from seed %d: %s" % (N_CASES, SEED0, tally))
+    print("device vs REAL reference: %d cases from seed %d + %d pinned: %s" % (N_CASES, SEED0, len(PINNED_SEEDS), tally))
     if bad:                                             # the whole story, not pytest's shortened repr
         import json
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

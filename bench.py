@@ -388,7 +388,9 @@ def config5_pass(lib, nframes):
             # the same byte formulas summed by the device coder over all launches of the sequence / the
             # HIP-event time of those launches; kernel fiasco_frame_kernel_big_wide (30 frames x 8 workgroups per launch)
             "roofline": {"bound": "hbm", "achieved": alg / ks5 / 1e9 if ks5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / ks5 / 1e9 / HBM_PEAK_GBS if ks5 else None, "traffic": None,
+                         "frac": alg / ks5 / 1e9 / HBM_PEAK_GBS if ks5 else None,
+                         # the 14 launches of the sequence together (whole job), as `algorithmic_bytes` is
+                         "traffic": pmc_traffic(nframes, 1280, 720, True)[0], "traffic_source": pmc_traffic(nframes, 1280, 720, True)[1],
                          "kernel": "fiasco_frame_kernel_big_wide", "algorithmic_bytes": alg},
             "all_encoded": ok, "seconds": dt, "frames_per_s": nframes / dt if ok else None, "bytes": len(data),
             "kernel_seconds": st.kernel_ms / 1e3, "launches": int(st.launches), "reencoded_frames": int(st.reencodes),

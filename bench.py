@@ -233,7 +233,7 @@ def launch_form(lib, frames, w, h, cus=256):
     """The launcher's choice for a launch of `frames` gray frames of w x h on one GPU (pure policy functions of the
     library, include/libfiasco_amd_hip.h): kernel build, workgroups per frame, append helpers per frame."""
     big = 1 if max(w, h) > 2048 else 0
-    g = int(lib.L.fiasco_amd_spec_workgroups(frames, cus, big, 0 if big else 1, 1 if big else 5))
+    g = int(lib.L.fiasco_amd_spec_workgroups(frames, cus, big, 0 if big else 1, 1 if big else 4))
     if g:
         build = "fiasco_frame_kernel_spec_wide (1024 threads)" if big else "fiasco_frame_kernel_spec (256 threads)"
         return {"frames": frames, "kernel_build": build, "workgroups_per_frame": g,

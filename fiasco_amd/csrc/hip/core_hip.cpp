@@ -913,22 +913,28 @@ static int spec_groups(size_t frames, int cus, bool big_frames, bool narrow_only
 static int spec_policy(size_t frames, int cus, bool big_frames, bool narrow_only, int occ)
 {
     if (!frames || cus < 1) return 0;
-    /* by default a CU per workgroup while the frames leave five or more to each (measured, 1080p: 1 frame
-     * 3.3 x, 16 frames 2.9 x the rate of one wide workgroup per frame; more workgroups than that per frame
-     * and CU are slower: 48 frames x 6 on 256 CUs 89 frames/s, x 5 93), and at least two verifiers per
-     * chain (one keeps it waiting: slower than no speculation at all) */
+    /* a CU per workgroup while the frames leave that many, at most FC_SPEC_MAXG; at least two verifiers per chain (one
+     * keeps it waiting: slower than no speculation at all) */
     size_t G = (size_t) cus / frames;
     if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
-    /* Fewer than five: the third verifier and the table worker are worth more than a CU of one's own,
-     * and three workgroups per frame beat one for as long as the chip holds them side by side -- 256-thread
-     * build only, every workgroup resident (3 per CU: 12 waves, 84 KB LDS).  1080p frames/s, one wide
-     * workgroup per frame -> this: 56 frames 86 (x 4) -> 102 (x 5), 64: 98 (x 4) -> 113 (x 5), 80: 97 (x 3)
-     * -> 114 (x 4), 96: 75 -> 132 (x 4), 128: 100 -> 140 (x 3), 160: 124 -> 168, 200: 155 -> 182, 256: 197 ->
-     * 213.  (64 x 6: 101; 4 without a table worker: 80 frames 97, 64 frames 89.) */
-    if (narrow_only && !big_frames && G < 5 && occ >= 3) {
-        if (4 * 5 * frames <= 5 * (size_t) cus) G = 5;             /* 1.25 workgroups per CU */
-        else if (2 * 4 * frames <= 3 * (size_t) cus) G = 4;        /* 1.5 */
-        else if (frames <= (size_t) cus) G = 3;                    /* 3 */
+    /* The 256-thread build shares CUs (four workgroups each): as many workgroups per frame as are resident, but not
+     * more than five once the launch passes 2.5 workgroups per CU.  Round 6 (hand-offs with one releasing lane;
+     * tests/gpu_spec_policy_sweep.sh, 1080p frames/s by workgroups per frame):
+     *   frames      3      4      5      6      8     one workgroup each
+     *     48       61     76     99     98    104      39
+     *     64       81    101    128    127    132      52
+     *     96      114    144    186    181    177      78
+     *    128      148    189    228    231    203     103
+     *    192      195    250    299      (5 is what fits)  154
+     *    256      245    275      (4 is what fits)         206
+     * (until round 5, when every lane fenced at every hand-off: 5 / 4 / 3 for 64 / 96 / 256 frames -- 113, 132, 213.) */
+    if (narrow_only && !big_frames && occ >= 2) {
+        G = (size_t) cus * (size_t) occ / frames;
+        if (G > FC_SPEC_MAXG) G = FC_SPEC_MAXG;
+        if (G > 5 && 2 * frames * G > 5 * (size_t) cus) {
+            G = 5 * (size_t) cus / (2 * frames);
+            if (G < 5) G = 5;
+        }
     }
     /* (Until round 5 4K frames were kept to half the CUs -- 32 frames: 7.2 frames/s with 8 workgroups each, 9.1 with 4:
      * every lane of every workgroup fenced at each hand-off and the L2 write-backs slowed everybody down.  With one

@@ -3725,9 +3725,9 @@ __device__ void spec_tables(DevFrame &__restrict__ F, Sh &__restrict__ sh, int b
             sh.tab_shared = 0; sl.n_tab_missed++; from = 0;
         }
         sh.tab_from = from;
+        take_acquire();                 /* the worker's entries, not this CU's stale lines (one lane; the barrier follows) */
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     /* the worker's entries, not this CU's stale lines */
 }
 #endif
 
@@ -3786,8 +3786,7 @@ __device__ __noinline__ void spec_worker(DevFrame &__restrict__ F, Sh &__restric
             }
         }
         __syncthreads();
-        if (!tw_go) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!tw_go) break;              /* (lane 0's acquire loads of epoch / s_pub have dropped this CU's L1) */
         op_init_range(F, sh, tw_x, tw_y, 0);
         WAVE_DRAIN();
         __syncthreads();

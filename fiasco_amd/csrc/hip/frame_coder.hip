@@ -361,7 +361,7 @@ struct Sh {
      * OP_PRED_SETUP / OP_PRED_FINISH); the other set rests in dpool / dcb / dq. */
     Pool     dpool;
     CoeffBuf dcb;
-    struct { int rpf_mant, dc_mant, sy, dcs; float rpf_range, dc_range; } dq;
+    struct { int rpf_mant, dc_mant, sy, dcs; float rpf_range, dc_range; int half_nd, half_dc; } dq;
     int      nslot;                /* aac snapshot slots per depth: 2, or 5 with prediction */
     uint4   *snap_tm_p;            /* tree-model snapshots: snap_tm, or HBM with prediction */
     int      pred_active, pred_lo, pred_rec;   /* a residual search is running; displaced ids */
@@ -450,6 +450,9 @@ struct Sh {
         int16_t *at_tree, *at_into, *at_pool; float *at_weight, *at_final; uint8_t *at_los, *at_dtype, *at_ycol;
         uint16_t *at_x, *at_y; int color;
         float rpf_range, dc_range;
+        /* rtob(0.5) in the two RPF formats of the ACTIVE coefficient model: the symbol of the placeholder weight of
+         * the stage-1 estimates (codec/approx.c:457) -- a constant of the frame (and of the model set), not of the call */
+        int half_nd, half_dc;
     } par;
 #if FC_GM
     /* generic models (frame_coder.h FC_GM): kinds of the ACTIVE [0] and the resting [1] model set (pool, coefficients),
@@ -2052,6 +2055,8 @@ __device__ void swap_model_sets(Sh &sh)
         i = sh.par.dcs; sh.par.dcs = sh.dq.dcs; sh.dq.dcs = i;
         f = sh.par.rpf_range; sh.par.rpf_range = sh.dq.rpf_range; sh.dq.rpf_range = f;
         f = sh.par.dc_range; sh.par.dc_range = sh.dq.dc_range; sh.dq.dc_range = f;
+        i = sh.par.half_nd; sh.par.half_nd = sh.dq.half_nd; sh.dq.half_nd = i;
+        i = sh.par.half_dc; sh.par.half_dc = sh.dq.half_dc; sh.dq.half_dc = i;
     }
 }
 
@@ -4225,6 +4230,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
 #endif
         sh.dq.rpf_mant = F.d_rpf_mant; sh.dq.dc_mant = F.d_dc_mant; sh.dq.sy = F.d_sy; sh.dq.dcs = F.d_dcs;
         sh.dq.rpf_range = F.d_rpf_range; sh.dq.dc_range = F.d_dc_range;
+        sh.dq.half_nd = rtob_dev(0.5f, F.d_rpf_mant, F.d_rpf_range); sh.dq.half_dc = rtob_dev(0.5f, F.d_dc_mant, F.d_dc_range);
         if (F.pred_on && F.d_coeff_size > FC_MAXCOEFF_BIG) sh.failed = FC_ERR_INTERNAL;
 #endif
 #if FC_VARIANT_BIG
@@ -4250,6 +4256,7 @@ FC_KERNEL(DevFrame *frames, unsigned nlend, unsigned long long *ring, unsigned *
         sh.par.sy = F.sy; sh.par.dcs = F.dcs; sh.par.gl0 = F.gl0; sh.par.images_level = F.images_level;
         sh.par.lc_min_opt = F.lc_min; sh.par.trace_on = F.trace != nullptr;
         sh.par.rpf_range = F.rpf_range; sh.par.dc_range = F.dc_range;
+        sh.par.half_nd = rtob_dev(0.5f, F.rpf_mant, F.rpf_range); sh.par.half_dc = rtob_dev(0.5f, F.dc_mant, F.dc_range);
         sh.band = 0; sh.lc_min = F.lc_min; sh.after_chroma = 0; sh.ystates = 0;
         push_root(F, sh, RANGE_);
         sh.op = OP_NOP;                      /* first pass: no parallel op, just run the search */

@@ -278,6 +278,10 @@ struct MPState {
     int   n, best_n, index, D, N, level, image, address, row_state;
     short indices[MAXED + 1], into[MAXED + 1];
     float weight[MAXED];
+    /* the RPF symbols of weight[0..2] as full_eval quantised them (SYMP_*; rtob(btor(sym)) == sym: what mp_step_prepare
+     * and models_update would compute from the weights again, ~45 instructions of the serial lane apiece); an entry
+     * that is not known is 0 (the scans with scratch in HBM do not carry them) */
+    unsigned symp;
     float matrix_bits, weights_bits, err, costs, min_costs;
     float sel_ipdo[MAXED][MAXED];
     float norm_ov[MAXED + 1], ipio[MAXED + 1];
@@ -338,7 +342,14 @@ struct RoundBox {                    /* mp_reg.inc: winner of the running step, 
     float cost, mbits, wbits, err, f[MAXED];
     float num, den, ip[MAXED - 1];
     unsigned evals, blockevals;
+    unsigned symp;                   /* MPState::symp of the winner's weights */
 };
+/* sym + 2 in 10 bits per weight (sym = -1 .. 511); 0 = not known: that entry is quantised again (rtob) by whoever needs it
+ * -- e.g. a weight left over from another run of the same call under full_search (codec/approx.c:439-446) */
+#define SYMP_NONE 0u
+#define SYMP_HAS(p, k) ((k) < 3 && (((p) >> (10 * (k))) & 1023u) != 0u)
+#define SYMP_GET(p, k) ((int) (((p) >> (10 * (k))) & 1023u) - 2)
+#define SYMP_PUT(sym, k) ((unsigned) ((sym) + 2) << (10 * (k)))
 
 struct Sh {
     RoundBox rb;
@@ -405,7 +416,9 @@ struct Sh {
      * rewritten whenever that id is created again after a removal, so it always fits the dictionary. */
     unsigned short cum[NBLOCKMIN + 2];
 #endif
-    float    pixels[FC_PIXELS];
+    /* 16-byte aligned: op_d5 reads the block's pixels with 128-bit LDS loads (a member added in front of them in round 6
+     * shifted them by four bytes: init_range +10 %) */
+    __attribute__((aligned(16))) float pixels[FC_PIXELS];
     float    norms[FC_PIXELS / 32];  /* squared norms of the sub-blocks, heap order (NS <= 127) */
     unsigned long long tk[16];     /* ticks per op (lane 0) */
     struct {

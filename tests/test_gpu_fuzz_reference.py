@@ -58,6 +58,9 @@ def make_case(seed, td):
     rng = np.random.default_rng(seed)
     colour = bool(rng.integers(0, 3) == 0)
     video = bool(rng.integers(0, 2))
+    if os.environ.get("FUZZ_REF_VIDEO") == "1":         # long runs: colour videos (the level ratchet, the reference frames)
+        colour = bool(rng.integers(0, 3) != 0)
+        video = True
     pattern, nfr, extra = "i", int(rng.choice([1, 1, 1, 2, 3])), []
     if video:
         pattern = str(rng.choice(["ip", "ipp", "ippp", "ibp", "ibbp", "ipb", "ipbbp"]))
